@@ -1,0 +1,234 @@
+"""Generate the committed golden vectors by running the REFERENCE modules.
+
+Run only where /root/reference exists (never on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's `surgical_world_model` (torch + numpy only) and, with inert
+placeholder modules for the absent `cv2`/`torchvision` (only the dataset classes touch them),
+`stage1_surgvu_pretraining` for `StructuredTemporalMasking.future_masking`.  Every reference
+output is first compared with the CPU oracle (`oracle/ref_cpu.py`); the script aborts if they
+disagree, so a committed fixture also certifies the oracle.  Outputs: small `.npz` files in this
+directory holding inputs, expected outputs and gradient checksums.  Model weights are NOT stored
+(the encoder only exists at width 1024): they are re-created from the closed-form fill
+`oracle.ref_cpu.fill_state_dict_`, keyed by state-dict name.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from oracle import ref_cpu as R  # noqa: E402
+
+import surgical_world_model as swm  # noqa: E402  (the reference)
+
+torch.set_num_threads(8)
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def close(a, b, what, rtol=2e-5, atol=2e-5):
+    if not torch.allclose(a, b, rtol=rtol, atol=atol):
+        raise SystemExit(f"oracle != reference for {what}: max abs diff {(a - b).abs().max().item():.3e}")
+    print(f"  ok {what}: max abs diff {(a - b).abs().max().item():.3e}")
+
+
+def grad_digest(g: torch.Tensor, name: str):
+    """sum, abs-sum and 64 sampled elements (sample positions from the name hash)."""
+    flat = g.reshape(-1).double()
+    n = flat.numel()
+    rng = np.random.default_rng(R._name_seed(name) % (1 << 32))
+    pos = np.sort(rng.integers(0, n, size=min(64, n)))
+    return np.array([flat.sum().item(), flat.abs().sum().item()]), pos.astype(np.int64), flat[pos].numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"wrote {name} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def gen_rope():
+    out = {}
+    for grid in [(2, 2, 2), (8, 14, 14), (8, 16, 16), (32, 16, 16)]:
+        rope = swm.VideoRoPE3D(1024, 256, 384, 384, temporal_scale=0.6)
+        ref = rope(*grid)
+        mine = R.rope_tables(*grid)
+        tag = "x".join(map(str, grid))
+        for (rc, rs), (mc, ms), ax in zip(ref, mine, "thw"):
+            assert torch.equal(rc, mc) and torch.equal(rs, ms), f"rope table {tag} {ax}"
+            # full tables are tiny for (2,2,2); for others keep digests
+            if grid == (2, 2, 2):
+                out[f"cos_{ax}_{tag}"] = rc
+                out[f"sin_{ax}_{tag}"] = rs
+            out[f"digest_{ax}_{tag}"] = np.array([rc.double().sum().item(), rs.double().sum().item(),
+                                                  rc.double().abs().sum().item(), rs.double().abs().sum().item()])
+        enc = swm.VideoViTEncoder.__new__(swm.VideoViTEncoder)
+        pos = swm.VideoViTEncoder._create_token_positions(enc, *grid, device="cpu")
+        t, h, w = R.token_coords(*grid)
+        assert torch.equal(pos["t_idx"], t) and torch.equal(pos["h_idx"], h) and torch.equal(pos["w_idx"], w)
+        out[f"pos_digest_{tag}"] = np.array([t.sum().item(), h.sum().item(), w.sum().item(),
+                                             (t * torch.arange(len(t))).sum().item(),
+                                             (h * torch.arange(len(t))).sum().item(),
+                                             (w * torch.arange(len(t))).sum().item()], dtype=np.int64)
+    print("  ok rope tables + token positions: bit-exact")
+    save("rope.npz", **out)
+
+
+def gen_tubelet():
+    te = swm.TubeletEmbedding(img_size=32, num_frames=4, tubelet_size=(2, 16, 16), in_channels=3, embed_dim=1024)
+    sd = R.fill_state_dict_({"tubelet_embed." + k: v for k, v in te.state_dict().items()})
+    te.load_state_dict({k[len("tubelet_embed."):]: v for k, v in sd.items()})
+    video = R.hashed_uniform("golden.tubelet.video", (1, 3, 4, 32, 32), 1.0)
+    ref = te(video)
+    mine = R.tubelet_embed(video, sd["tubelet_embed.projection.weight"], sd["tubelet_embed.projection.bias"])
+    close(ref, mine, "tubelet embed")
+    save("tubelet.npz", video=video, out=ref)
+
+
+def gen_attention():
+    out = {}
+    grid = (2, 2, 2)
+    N = 8
+    for heads in (16, 8):
+        for masked in (False, True):
+            att = swm.RoPEMultiheadAttention(1024, heads, rope_dims={"t_dim": 256, "h_dim": 384, "w_dim": 384}).eval()
+            sd = R.fill_state_dict_({"blocks.0.attn." + k: v for k, v in att.state_dict().items()})
+            att.load_state_dict({k[len("blocks.0.attn."):]: v for k, v in sd.items()})
+            x = R.hashed_uniform(f"golden.attn.x.{heads}", (2, N, 1024), 1.0).requires_grad_(True)
+            rope = swm.VideoRoPE3D(1024)(*grid)
+            enc = swm.VideoViTEncoder.__new__(swm.VideoViTEncoder)
+            pos = swm.VideoViTEncoder._create_token_positions(enc, *grid, device="cpu")
+            mask = None
+            if masked:
+                mask = torch.triu(torch.ones(N, N, dtype=torch.bool), diagonal=1)
+            y = att(x, rope_cache=rope, token_positions=pos, attn_mask=mask)
+            gy = R.hashed_uniform("golden.attn.gy", y.shape, 1.0)
+            (y * gy).sum().backward()
+            x2 = x.detach().clone().requires_grad_(True)
+            wq = sd["blocks.0.attn.qkv_proj.weight"].clone().requires_grad_(True)
+            wo = sd["blocks.0.attn.out_proj.weight"].clone().requires_grad_(True)
+            y2 = R.rope_attention(x2, wq, wo, heads, grid, mask)
+            (y2 * gy).sum().backward()
+            tag = f"h{heads}_{'mask' if masked else 'nomask'}"
+            close(y, y2, f"attention out {tag}")
+            close(x.grad, x2.grad, f"attention dx {tag}", atol=1e-4)
+            close(att.qkv_proj.weight.grad, wq.grad, f"attention dWqkv {tag}", atol=1e-4)
+            close(att.out_proj.weight.grad, wo.grad, f"attention dWout {tag}", atol=1e-4)
+            out[f"x_{tag}"] = x.detach()
+            out[f"gy_{tag}"] = gy
+            out[f"y_{tag}"] = y.detach()
+            out[f"dx_{tag}"] = x.grad
+            for nm, g in (("dwqkv", att.qkv_proj.weight.grad), ("dwout", att.out_proj.weight.grad)):
+                d, p, v = grad_digest(g, f"{nm}_{tag}")
+                out[f"{nm}_{tag}_digest"], out[f"{nm}_{tag}_pos"], out[f"{nm}_{tag}_val"] = d, p, v
+    save("attention.npz", **out)
+
+
+def gen_encoder():
+    for depth, heads, B, frames, img in ((1, 16, 1, 4, 32), (2, 16, 2, 4, 32), (2, 8, 1, 4, 48)):
+        enc = swm.VideoViTEncoder(img_size=img, num_frames=frames, embed_dim=1024, depth=depth, num_heads=heads).eval()
+        shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items() if "inv_freq" not in k}
+        assert shapes == R.encoder_param_shapes(depth), "state-dict keys/shapes differ from oracle list"
+        sd = R.fill_state_dict_(enc.state_dict())
+        enc.load_state_dict(sd)
+        video = R.hashed_uniform(f"golden.enc.video.{depth}.{heads}", (B, 3, frames, img, img), 1.0).requires_grad_(True)
+        y = enc(video)
+        gy = R.hashed_uniform("golden.enc.gy", y.shape, 1.0)
+        (y * gy).sum().backward()
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items() if "inv_freq" not in k}
+        v2 = video.detach().clone().requires_grad_(True)
+        y2 = R.encoder_forward(P, v2, depth, heads)
+        (y2 * gy).sum().backward()
+        tag = f"d{depth}h{heads}"
+        close(y, y2, f"encoder out {tag}", atol=1e-4)
+        close(video.grad, v2.grad, f"encoder dvideo {tag}", atol=1e-4, rtol=1e-4)
+        out = dict(video=video.detach(), gy=gy, y=y.detach(), dvideo=video.grad,
+                   cfg=np.array([depth, heads, B, frames, img], dtype=np.int64))
+        for k, p in enc.named_parameters():
+            close(p.grad, P[k].grad, f"encoder grad {tag} {k}", atol=2e-4, rtol=1e-4)
+            d, pos, val = grad_digest(p.grad, k)
+            out[f"g:{k}:digest"], out[f"g:{k}:pos"], out[f"g:{k}:val"] = d, pos, val
+        save(f"encoder_{tag}.npz", **out)
+
+
+def gen_seed_canary():
+    torch.manual_seed(0)
+    enc = swm.VideoViTEncoder(img_size=32, num_frames=4, embed_dim=1024, depth=1, num_heads=16).eval()
+    x = torch.randn(1, 3, 4, 32, 32, generator=torch.Generator().manual_seed(1))
+    y = enc(x)
+    loss = (y ** 2).mean()
+    loss.backward()
+    save("seed_canary.npz",
+         y_abs_sum=y.detach().double().abs().sum().item(), y_head=y[0, 0, :8].detach(),
+         conv_w_sum=enc.tubelet_embed.projection.weight.double().sum().item(),
+         qkv_w_sum=enc.blocks[0].attn.qkv_proj.weight.double().sum().item(),
+         fc1_w_sum=enc.blocks[0].mlp[0].weight.double().sum().item(),
+         fc2_b_sum=enc.blocks[0].mlp[3].bias.double().sum().item(),
+         dqkv_l1=enc.blocks[0].attn.qkv_proj.weight.grad.double().abs().sum().item(),
+         keys=np.array(list(enc.state_dict().keys())))
+
+
+def gen_masking():
+    for m in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    import stage1_surgvu_pretraining as s1  # the reference script (dataset classes unused)
+    out = {}
+    for Tp in (4, 5, 8, 32):
+        for ratio in (0.5, 0.75, 0.9):
+            per = 3
+            x = R.hashed_uniform("golden.mask.x", (2, Tp * per, 8), 1.0)
+            rm, rmask = s1.StructuredTemporalMasking.future_masking(x, Tp, ratio)
+            mm, mmask = R.future_masking(x, Tp, ratio)
+            assert torch.equal(rmask, mmask) and torch.equal(rm, mm), (Tp, ratio)
+            out[f"mask_T{Tp}_r{ratio}"] = rmask[0].numpy()
+    print("  ok future_masking: bit-exact for all (T, ratio)")
+    save("future_masking.npz", **out)
+
+    # one stage-1 loss evaluation on fixed features (dropout disabled) through the reference heads
+    torch.manual_seed(3)
+    B, N, D, Tp = 4, 8, 1024, 2
+    tc = torch.nn.Sequential(torch.nn.Linear(D, D // 2), torch.nn.ReLU(), torch.nn.Dropout(0.0), torch.nn.Linear(D // 2, 2))
+    cp = torch.nn.Sequential(torch.nn.Linear(D, D), torch.nn.ReLU(), torch.nn.Linear(D, 128))
+    dh = torch.nn.Sequential(torch.nn.LayerNorm(D), torch.nn.Linear(D, D), torch.nn.GELU(), torch.nn.Linear(D, D))
+    heads = {}
+    for pre, mod in (("temporal_classifier.", tc), ("contrastive_proj.", cp), ("denoise_head.", dh)):
+        filled = R.fill_state_dict_({pre + k: v for k, v in mod.state_dict().items()})
+        mod.load_state_dict({k[len(pre):]: v for k, v in filled.items()})
+        heads.update(filled)
+    feats = [R.hashed_uniform(f"golden.s1.f{i}", (B, N, D), 1.0) for i in range(4)]
+    label = torch.tensor([0, 1, 1, 0])
+    import torch.nn.functional as F
+    l_t = F.cross_entropy(tc(feats[0].mean(1)), label)
+    z1 = F.normalize(cp(feats[1].mean(1)), dim=1)
+    z2 = F.normalize(cp(feats[2].mean(1)), dim=1)
+    lab = torch.arange(B)
+    l_c = 0.5 * (F.cross_entropy(z1 @ z2.t() / 0.07, lab) + F.cross_entropy(z2 @ z1.t() / 0.07, lab))
+    masked, mb = s1.StructuredTemporalMasking.future_masking(feats[3], Tp, 0.5)
+    keep = ~mb
+    pooled = (masked * keep.unsqueeze(-1)).sum(1) / keep.sum(1, keepdim=True).clamp_min(1)
+    l_m = F.mse_loss(dh(pooled), feats[3].mean(1))
+    total = l_t + l_c + 0.1 * l_m
+    mine, parts = R.stage1_losses(feats[0], feats[1], feats[2], feats[3], label, heads, Tp)
+    close(total, mine, "stage-1 total loss")
+    save("stage1_losses.npz", total=total.item(), l_t=l_t.item(), l_c=l_c.item(), l_m=l_m.item(), label=label.numpy())
+
+
+if __name__ == "__main__":
+    with torch.enable_grad():
+        gen_rope()
+        gen_tubelet()
+        gen_attention()
+        gen_encoder()
+        gen_seed_canary()
+        gen_masking()
+    print("all golden vectors written")

@@ -1,0 +1,120 @@
+"""CPU: the oracle (oracle/ref_cpu.py) against the committed reference outputs in tests/golden."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_rope_tables_bit_exact(golden_dir):
+    g = _load(golden_dir, "rope.npz")
+    for grid in [(2, 2, 2), (8, 14, 14), (8, 16, 16), (32, 16, 16)]:
+        tag = "x".join(map(str, grid))
+        tabs = R.rope_tables(*grid)
+        for (c, s), ax in zip(tabs, "thw"):
+            d = np.array([c.double().sum().item(), s.double().sum().item(),
+                          c.double().abs().sum().item(), s.double().abs().sum().item()])
+            np.testing.assert_array_equal(d, g[f"digest_{ax}_{tag}"])
+        t, h, w = R.token_coords(*grid)
+        ar = torch.arange(len(t))
+        d = np.array([t.sum().item(), h.sum().item(), w.sum().item(),
+                      (t * ar).sum().item(), (h * ar).sum().item(), (w * ar).sum().item()], dtype=np.int64)
+        np.testing.assert_array_equal(d, g[f"pos_digest_{tag}"])
+    for ax, (c, s) in zip("thw", R.rope_tables(2, 2, 2)):
+        np.testing.assert_array_equal(c.numpy(), g[f"cos_{ax}_2x2x2"])
+        np.testing.assert_array_equal(s.numpy(), g[f"sin_{ax}_2x2x2"])
+
+
+def test_tubelet(golden_dir):
+    g = _load(golden_dir, "tubelet.npz")
+    sd = R.fill_state_dict_({"tubelet_embed.projection.weight": torch.empty(1024, 3, 2, 16, 16),
+                             "tubelet_embed.projection.bias": torch.empty(1024)})
+    y = R.tubelet_embed(torch.from_numpy(g["video"]), sd["tubelet_embed.projection.weight"],
+                        sd["tubelet_embed.projection.bias"])
+    np.testing.assert_allclose(y.numpy(), g["out"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("heads", [16, 8])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention(golden_dir, heads, masked):
+    g = _load(golden_dir, "attention.npz")
+    tag = f"h{heads}_{'mask' if masked else 'nomask'}"
+    sd = R.fill_state_dict_({"blocks.0.attn.qkv_proj.weight": torch.empty(3072, 1024),
+                             "blocks.0.attn.out_proj.weight": torch.empty(1024, 1024)})
+    x = torch.from_numpy(g[f"x_{tag}"]).requires_grad_(True)
+    wq = sd["blocks.0.attn.qkv_proj.weight"].requires_grad_(True)
+    wo = sd["blocks.0.attn.out_proj.weight"].requires_grad_(True)
+    mask = torch.triu(torch.ones(8, 8, dtype=torch.bool), diagonal=1) if masked else None
+    y = R.rope_attention(x, wq, wo, heads, (2, 2, 2), mask)
+    (y * torch.from_numpy(g[f"gy_{tag}"])).sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), g[f"y_{tag}"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g[f"dx_{tag}"], rtol=1e-4, atol=1e-4)
+    for nm, p in (("dwqkv", wq), ("dwout", wo)):
+        flat = p.grad.reshape(-1).double()
+        np.testing.assert_allclose(flat[g[f"{nm}_{tag}_pos"]].numpy(), g[f"{nm}_{tag}_val"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(flat.abs().sum().item(), g[f"{nm}_{tag}_digest"][1], rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["d1h16", "d2h16", "d2h8"])
+def test_encoder_fwd_bwd(golden_dir, tag):
+    g = _load(golden_dir, f"encoder_{tag}.npz")
+    depth, heads, B, frames, img = (int(v) for v in g["cfg"])
+    P = R.make_encoder_params(depth, requires_grad=True)
+    video = torch.from_numpy(g["video"]).requires_grad_(True)
+    y = R.encoder_forward(P, video, depth, heads)
+    (y * torch.from_numpy(g["gy"])).sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(video.grad.numpy(), g["dvideo"], rtol=1e-4, atol=1e-4)
+    for k, p in P.items():
+        flat = p.grad.reshape(-1).double()
+        np.testing.assert_allclose(flat[g[f"g:{k}:pos"]].numpy(), g[f"g:{k}:val"], rtol=2e-4, atol=2e-4, err_msg=k)
+        np.testing.assert_allclose(flat.abs().sum().item(), g[f"g:{k}:digest"][1], rtol=1e-4, err_msg=k)
+
+
+def test_future_masking_bit_exact(golden_dir):
+    g = _load(golden_dir, "future_masking.npz")
+    for Tp in (4, 5, 8, 32):
+        for ratio in (0.5, 0.75, 0.9):
+            x = R.hashed_uniform("golden.mask.x", (2, Tp * 3, 8), 1.0)
+            masked, mask = R.future_masking(x, Tp, ratio)
+            np.testing.assert_array_equal(mask[0].numpy(), g[f"mask_T{Tp}_r{ratio}"])
+            np.testing.assert_array_equal(mask[1].numpy(), g[f"mask_T{Tp}_r{ratio}"])
+            assert torch.equal(masked[~mask], x[~mask]) and (masked[mask] == 0).all()
+    # the cut-off arithmetic: int(8*(1-0.9)) == 0 masks everything
+    assert g["mask_T8_r0.9"].all()
+
+
+def test_stage1_losses(golden_dir):
+    g = _load(golden_dir, "stage1_losses.npz")
+    B, N, D, Tp = 4, 8, 1024, 2
+    shapes = {"temporal_classifier.0.weight": (D // 2, D), "temporal_classifier.0.bias": (D // 2,),
+              "temporal_classifier.3.weight": (2, D // 2), "temporal_classifier.3.bias": (2,),
+              "contrastive_proj.0.weight": (D, D), "contrastive_proj.0.bias": (D,),
+              "contrastive_proj.2.weight": (128, D), "contrastive_proj.2.bias": (128,),
+              "denoise_head.0.weight": (D,), "denoise_head.0.bias": (D,),
+              "denoise_head.1.weight": (D, D), "denoise_head.1.bias": (D,),
+              "denoise_head.3.weight": (D, D), "denoise_head.3.bias": (D,)}
+    heads = R.fill_state_dict_({k: torch.empty(v) for k, v in shapes.items()})
+    feats = [R.hashed_uniform(f"golden.s1.f{i}", (B, N, D), 1.0) for i in range(4)]
+    total, (l_t, l_c, l_m) = R.stage1_losses(*feats, torch.from_numpy(g["label"]), heads, Tp)
+    np.testing.assert_allclose(total.item(), g["total"], rtol=1e-5)
+    np.testing.assert_allclose([l_t.item(), l_c.item(), l_m.item()], [g["l_t"], g["l_c"], g["l_m"]], rtol=1e-5)
+
+
+def test_jepa_masks_are_seeded_and_disjoint():
+    c1, t1 = R.jepa_block_masks(7, 4, (8, 16, 16))
+    c2, t2 = R.jepa_block_masks(7, 4, (8, 16, 16))
+    assert torch.equal(c1, c2) and torch.equal(t1, t2)
+    assert c1.dtype == torch.int32 and t1.dtype == torch.int32
+    for b in range(4):
+        assert not set(c1[b].tolist()) & set(t1[b].tolist())
+        assert (c1[b][1:] > c1[b][:-1]).all() and (t1[b][1:] > t1[b][:-1]).all()
+    x = R.hashed_uniform("x", (4, 2048, 16), 1.0)
+    back = R.token_scatter(R.token_gather(x, t1), t1, 2048)
+    assert torch.equal(R.token_gather(back, t1), R.token_gather(x, t1))
