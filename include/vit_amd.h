@@ -1,0 +1,131 @@
+/* libvit_amd: C ABI of the MI355X (gfx950) kernels behind the video-ViT encoder hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers and sizes; no framework types.  Pointers are borrowed for the duration of
+ *     the call's enqueued work; nothing is retained, allocated, freed or synchronised by the library.
+ *   - all work is enqueued on `stream` (a hipStream_t; NULL = the default stream).
+ *   - return 0 on success, a negative VA_ERR_* code otherwise; va_last_error() then describes it
+ *     (thread-local string).  Nothing throws across the boundary.
+ *   - bf16 tensors are raw 16-bit words; "f32" is IEEE binary32.  Row-major; `ld*` are leading
+ *     dimensions in ELEMENTS.  16-byte alignment of every tensor base is required.
+ *
+ * Each declaration names the reference code it stands in for.  Citations are into the reference
+ * repository (HananKibria/VIT): swm = surgical_world_model.py, s1 = stage1_surgvu_pretraining.py.
+ */
+#ifndef VIT_AMD_H
+#define VIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* va_stream_t; /* == hipStream_t */
+
+#define VA_ERR_INVALID_ARG (-1)
+#define VA_ERR_LAUNCH_FAILED (-2)
+#define VA_ERR_UNSUPPORTED_SHAPE (-3)
+
+/* GEMM epilogues */
+#define VA_EPI_BF16 0      /* out(bf16) = acc [+ bias]                                   */
+#define VA_EPI_BIAS_GELU 1 /* out(bf16) = acc + bias ; out2(bf16) = gelu_erf(acc + bias)  */
+#define VA_EPI_F32 2       /* out(f32)  = acc [+ bias] [+ resid(f32)]                     */
+#define VA_EPI_GELU_BWD 3  /* out(bf16) = acc * gelu_erf'(aux(bf16))                      */
+
+int va_version(void);
+const char* va_last_error(void);
+
+/* ---- dense projections ------------------------------------------------------------------------
+ * out[M,N] = x[M,K] * w[N,K]^T with a fused epilogue; bf16 operands, f32 accumulation on MFMA.
+ * Replaces nn.Linear forward for qkv_proj / out_proj (swm:296, 334), the MLP (swm:698-701), the
+ * Conv3d patch projection once patches are gathered (swm:102), and the data-gradient half of their
+ * autograd backward (with w = a transposed copy of the weight).  K % 64 == 0, N % 128 == 0.
+ * `tile`: 0 = choose, 128 or 256 = force the workgroup tile edge. */
+int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+               int epilogue, void* out, void* out2, const float* bias, const float* resid, const void* aux,
+               int64_t ldc, int tile, va_stream_t stream);
+
+/* dw[N,K] (f32) += dy[M,N]^T * x[M,K]: the weight-gradient half of nn.Linear's backward (autograd of
+ * swm:296, 334, 698-701, 102).  bf16 operands, split over M in `split_k` slices (0 = choose) that are
+ * combined with f32 atomic adds, so `dw` must hold the value to accumulate onto (zeros for a fresh
+ * gradient).  N % 128 == 0, K % 128 == 0; any M. */
+int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t ldx,
+                     float* dw, int64_t lddw, int split_k, va_stream_t stream);
+
+/* out[N] (f32) += column sums of y[M,N] (bf16): bias gradients (autograd of swm:698, 701, 78). */
+int va_colsum_bf16_accum(const void* y, int64_t M, int64_t N, int64_t ldy, float* out, va_stream_t stream);
+
+/* ---- tubelet patch gather -----------------------------------------------------------------------
+ * video (B,C,T,H,W) f32 -> patches [B*Tp*Hp*Wp, C*tt*th*tw] bf16, row = token (t slowest, w fastest),
+ * columns ordered (c, dt, dh, dw) like a flattened Conv3d filter: the im2col of the non-overlapping
+ * Conv3d at swm:78-84 with the flatten/transpose of swm:108 folded in.  tw % 8 == 0. */
+int va_tubelet_gather(const float* video, void* patches, int64_t B, int64_t C, int64_t T, int64_t H, int64_t W,
+                      int64_t tt, int64_t th, int64_t tw, va_stream_t stream);
+
+/* ---- LayerNorm (nn.LayerNorm, eps 1e-6; swm:686, 695, 757) ---------------------------------------
+ * forward: x f32 [M,D] -> y (bf16 if out_bf16 else f32) [M,D]; also stores mean/rstd [M] for backward. */
+int va_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, float* mean,
+                     float* rstd, int64_t M, int64_t D, float eps, va_stream_t stream);
+/* backward: dy (bf16 if dy_bf16 else f32) [M,D]; dx_out(f32) = (resid_grad ? resid_grad : 0) + dLN/dx;
+ * dx_bf16 (optional) receives a bf16 copy of dx_out; partial[(2*nblk), D] f32 is workspace of
+ * va_layernorm_bwd_partial_rows(M) * 2 * D floats; dgamma/dbeta [D] f32 are overwritten. */
+int64_t va_layernorm_bwd_partial_rows(int64_t M);
+int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                     const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16, float* partial,
+                     float* dgamma, float* dbeta, int64_t M, int64_t D, va_stream_t stream);
+
+/* ---- 3D rotary embedding (swm:33-51, 265-281) ------------------------------------------------------
+ * In-place rotation of the Q and K thirds of a packed qkv buffer [M, 3*D] bf16 (D = 1024, column
+ * segments t:0-255, h:256-639, w:640-1023; partner of column i inside a segment of width d is i+d/2).
+ * Token n = m % (Tp*Hp*Wp) has coordinates (n/(Hp*Wp), (n/Wp)%Hp, n%Wp) (swm:760-770).  `tables` holds
+ * the half-width cos then sin tables [(Tp x 128) | (Hp x 192) | (Wp x 192)] cos, then the same for sin
+ * (values of swm:192-222).  inverse != 0 rotates by the negative angle (the backward of the rotation). */
+int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, int64_t Tp, int64_t Hp, int64_t Wp,
+                         int inverse, va_stream_t stream);
+
+/* ---- flash attention (swm:306-331: softmax(q k^T * hd^-0.5) v, no mask, eval-mode dropout) ---------
+ * q,k,v: bf16, element (b, n, h, d) at ((b*N + n)*ld + h*hd + d) of the respective base pointer (so the
+ * three thirds of one packed qkv buffer can be passed with ld = 3*D).  o likewise with ldo.
+ * lse2[b*H + h][n] f32 receives log2-sum-exp of the scaled scores (needed by the backward).
+ * hd in {64, 128}. */
+int va_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N, int64_t H,
+                int64_t hd, int64_t ldqkv, int64_t ldo, va_stream_t stream);
+/* backward of the same: given o, do (bf16, layout of o), lse2, writes dq, dk, dv (layout of q/k/v, ld =
+ * lddqkv).  delta[b*H+h][n] f32 is workspace of B*H*N floats. */
+int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2,
+                float* delta, void* dq, void* dk, void* dv, int64_t B, int64_t N, int64_t H, int64_t hd,
+                int64_t ldqkv, int64_t ldo, int64_t lddqkv, va_stream_t stream);
+
+/* ---- parameter casts -------------------------------------------------------------------------------
+ * f32 -> bf16 copy of `n` elements (master weights -> MFMA operands). */
+int va_cast_f32_bf16(const float* src, void* dst, int64_t n, va_stream_t stream);
+/* w f32 [R,C] -> wt bf16 [C,R] (transposed operand for the data-gradient GEMMs). R,C % 32 == 0. */
+int va_cast_transpose_f32_bf16(const float* w, void* wt, int64_t R, int64_t C, va_stream_t stream);
+
+/* ---- token masking ------------------------------------------------------------------------------------
+ * Deterministic future masking (s1:300-333): rows n >= cutoff*(N/Tp) of every batch item are zeroed,
+ * cutoff = (int)(Tp*(1-ratio)) computed by the caller; out [B,N,D] (elem_bytes 2 or 4), mask [B,N] u8. */
+int va_future_mask(const void* x, void* out, uint8_t* mask, int64_t B, int64_t N, int64_t D, int64_t elem_bytes,
+                   int64_t first_masked_row, va_stream_t stream);
+/* Row gather out[b,j,:] = x[b, idx[b,j], :] and its inverse scatter (out pre-zeroed by the call).
+ * No reference symbol: these serve JEPA-style context/target token selection. row_bytes % 16 == 0. */
+int va_token_gather(const void* x, const int32_t* idx, void* out, int64_t B, int64_t N_src, int64_t N_keep,
+                    int64_t row_bytes, va_stream_t stream);
+int va_token_scatter(const void* src, const int32_t* idx, void* out, int64_t B, int64_t N_dst, int64_t N_keep,
+                     int64_t row_bytes, va_stream_t stream);
+
+/* ---- EMA target update and L1 latent loss (no reference symbol; JEPA objective pieces) -----------------
+ * target <- m*target + (1-m)*online over n f32 elements; optional bf16 shadow of the new target. */
+int va_ema_update(float* target, const float* online, void* target_bf16, int64_t n, float momentum,
+                  va_stream_t stream);
+/* loss_sum[0] (f32, pre-zeroed by the call) = sum |pred - target|; grad (f32 or bf16 per grad_bf16, optional)
+ * = sign(pred - target) * grad_scale.  pred/target f32 or bf16 per in_bf16. */
+int va_l1_loss(const void* pred, const void* target, int in_bf16, float* loss_sum, void* grad, int grad_bf16,
+               float grad_scale, int64_t n, va_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT_AMD_H */

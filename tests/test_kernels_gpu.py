@@ -1,0 +1,295 @@
+"""GPU: every C-ABI kernel against a plain fp32 PyTorch / oracle computation of the same op.
+
+Inputs are rounded to bf16 first where the kernel consumes bf16, so differences come only from the
+accumulation order (f32 MFMA accumulate) and from the bf16 rounding of the stored output.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vit_amd import ops as _ops
+    return _ops
+
+
+def rnd(shape, dev, seed, scale=1.0, dtype=F32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+
+# ------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("M,N,K,tile", [(8, 1024, 1024, 128), (300, 3072, 1024, 128), (1000, 1024, 1536, 128),
+                                        (2048, 4096, 1024, 256), (2048 + 17, 1024, 4096, 256), (513, 3072, 1024, 256),
+                                        (4096, 1024, 1024, 0)])
+def test_gemm_nt_plain(ops, dev, M, N, K, tile):
+    x = rnd((M, K), dev, 1, dtype=BF16)
+    w = rnd((N, K), dev, 2, 1.0 / math.sqrt(K), dtype=BF16)
+    out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_BF16, out, tile=tile)
+    ref = x.float() @ w.float().t()
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out, ref) < 4e-3
+    # element-wise: bf16 rounding of an O(1) value
+    assert (out.float() - ref).abs().max().item() < 0.06
+
+
+def test_gemm_nt_layout_is_not_transposed(ops, dev):
+    """x = [I | 0] picks rows of w^T: catches a swapped row/column map that a random check could miss."""
+    M, N, K = 128, 256, 128
+    x = torch.zeros(M, K, dtype=BF16, device=dev)
+    x[torch.arange(M), torch.arange(M) % K] = 1
+    w = (torch.arange(N, device=dev)[:, None] * 3 + torch.arange(K, device=dev)[None, :] % 7).float()
+    w = (w % 61 - 30).to(BF16)
+    out = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_BF16, out, tile=128)
+    assert torch.equal(out.float(), (x.float() @ w.float().t()))
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_nt_epilogues(ops, dev, tile):
+    M, N, K = 700, 1024, 1024
+    x = rnd((M, K), dev, 3, dtype=BF16)
+    w = rnd((N, K), dev, 4, 1.0 / math.sqrt(K), dtype=BF16)
+    bias = rnd((N,), dev, 5, 0.5)
+    resid = rnd((M, N), dev, 6)
+    acc = x.float() @ w.float().t()
+    # f32 + bias + residual
+    out = torch.empty(M, N, dtype=F32, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_F32, out, bias=bias, resid=resid, tile=tile)
+    assert (out - (acc + bias + resid)).abs().max().item() < 2e-3
+    out = torch.empty(M, N, dtype=F32, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_F32, out, tile=tile)
+    assert (out - acc).abs().max().item() < 2e-3
+    # bias + exact GELU
+    pre = torch.empty(M, N, dtype=BF16, device=dev)
+    act = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_BIAS_GELU, pre, out2=act, bias=bias, tile=tile)
+    assert rel_err(pre, acc + bias) < 4e-3
+    assert rel_err(act, torch.nn.functional.gelu(acc + bias)) < 5e-3
+    # GELU backward epilogue
+    g = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_GELU_BWD, g, aux=pre, tile=tile)
+    p = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(p).backward(acc)
+    assert rel_err(g, p.grad) < 5e-3
+
+
+def test_gemm_nt_rejects_bad_shapes(ops, dev):
+    from vit_amd._lib import VitAmdError
+    x = torch.zeros(8, 100, dtype=BF16, device=dev)
+    w = torch.zeros(128, 100, dtype=BF16, device=dev)
+    with pytest.raises(VitAmdError):
+        ops.gemm_nt(x, w, ops.EPI_BF16, torch.empty(8, 128, dtype=BF16, device=dev))
+
+
+# ------------------------------------------------------------------------------ GEMM TN
+@pytest.mark.parametrize("M,N,K,split", [(8, 1024, 1024, 0), (64, 128, 128, 1), (1000, 3072, 1024, 0),
+                                         (4096 + 13, 128, 256, 1), (4096 + 13, 128, 256, 7), (8192, 1024, 4096, 0)])
+def test_gemm_tn(ops, dev, M, N, K, split):
+    dy = rnd((M, N), dev, 7, dtype=BF16)
+    x = rnd((M, K), dev, 8, dtype=BF16)
+    dw = torch.ones(N, K, dtype=F32, device=dev)
+    ops.gemm_tn_accum(dy, x, dw, split_k=split)
+    ref = dy.float().t() @ x.float() + 1.0
+    assert torch.isfinite(dw).all()
+    assert rel_err(dw, ref) < 1e-4
+    assert (dw - ref).abs().max().item() < 1e-3 * math.sqrt(M)
+
+
+def test_gemm_tn_layout(ops, dev):
+    """dy = one-hot rows: dw[n, :] must equal the x row selected for n (exact in f32)."""
+    M, N, K = 128, 128, 256
+    dy = torch.zeros(M, N, dtype=BF16, device=dev)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(0)).to(dev)
+    dy[torch.arange(M, device=dev), perm] = 1
+    x = rnd((M, K), dev, 9, dtype=BF16)
+    dw = torch.zeros(N, K, dtype=F32, device=dev)
+    ops.gemm_tn_accum(dy, x, dw, split_k=1)
+    ref = torch.zeros(N, K, device=dev)
+    ref[perm] = x.float()
+    assert torch.equal(dw, ref)
+
+
+def test_colsum(ops, dev):
+    y = rnd((3000, 4096), dev, 10, dtype=BF16)
+    out = torch.zeros(4096, dtype=F32, device=dev)
+    ops.colsum_accum(y, out)
+    assert (out - y.float().sum(0)).abs().max().item() < 1e-2
+
+
+# ------------------------------------------------------------------------------ attention
+def attn_reference(qkv, B, N, H):
+    D = qkv.shape[1] // 3
+    hd = D // H
+    q, k, v = (t.reshape(B, N, H, hd).permute(0, 2, 1, 3) for t in qkv.float().split(D, dim=1))
+    s = (q @ k.transpose(-1, -2)) * hd ** -0.5
+    p = s.softmax(-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * N, D)
+    lse2 = torch.logsumexp(s, dim=-1) * math.log2(math.e)
+    return o, lse2.reshape(B * H, N)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 8, 16), (1, 200, 16), (2, 1568, 16), (1, 2048, 16), (2, 18, 8), (1, 300, 8),
+                                   (1, 1024, 8)])
+def test_attention_fwd_bwd(ops, dev, B, N, H):
+    D = 1024
+    qkv = rnd((B * N, 3 * D), dev, 11, dtype=BF16)
+    out = torch.full((B * N, D), float("nan"), dtype=BF16, device=dev)
+    lse2 = torch.empty(B * H, N, dtype=F32, device=dev)
+    ops.attn_fwd(qkv, B, N, H, out, lse2)
+    leaf = qkv.float().requires_grad_(True)
+    ref_o, ref_lse = attn_reference(leaf, B, N, H)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out, ref_o) < 8e-3
+    assert (lse2 - ref_lse).abs().max().item() < 2e-2
+    d_out = rnd((B * N, D), dev, 12, dtype=BF16)
+    ref_o.backward(d_out.float())
+    dqkv = torch.full((B * N, 3 * D), float("nan"), dtype=BF16, device=dev)
+    ops.attn_bwd(qkv, out, d_out, lse2, dqkv, B, N, H)
+    assert torch.isfinite(dqkv.float()).all()
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert rel_err(dqkv[:, sl], leaf.grad[:, sl]) < 1.5e-2, name
+
+
+def test_attention_online_softmax_rescale(ops, dev):
+    """One key per tile spiked against one query forces the running-max rescale late in the sweep."""
+    B, N, H, D = 1, 512, 16, 1024
+    qkv = rnd((N, 3 * D), dev, 13, 0.3, dtype=BF16)
+    qkv[5, :64] = 4.0                   # query 5, head 0
+    qkv[300, D:D + 64] = 4.0            # key 300, head 0  (tile 4): score 64*16/8 = 128
+    qkv[450, D:D + 64] = 6.0            # key 450 (tile 7): even larger
+    out = torch.empty(N, D, dtype=BF16, device=dev)
+    lse2 = torch.empty(H, N, dtype=F32, device=dev)
+    ops.attn_fwd(qkv, B, N, H, out, lse2)
+    ref_o, _ = attn_reference(qkv, B, N, H)
+    assert rel_err(out, ref_o) < 8e-3
+    assert (out[5, :64].float() - ref_o[5, :64]).abs().max().item() < 3e-2
+
+
+# ------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M", [8, 1001, 16384])
+def test_layernorm_fwd_bwd(ops, dev, M):
+    D = 1024
+    x = rnd((M, D), dev, 14, 2.0) + 0.5
+    gamma = 1 + 0.1 * rnd((D,), dev, 15)
+    beta = 0.1 * rnd((D,), dev, 16)
+    mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    y32 = torch.empty(M, D, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, y32, mean, rstd)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    assert (y32 - ref).abs().max().item() < 2e-5
+    yb = torch.empty(M, D, dtype=BF16, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, yb, mean, rstd)
+    assert rel_err(yb, ref) < 4e-3
+    dy = rnd((M, D), dev, 17)
+    ref.backward(dy)
+    resid = rnd((M, D), dev, 18)
+    dx = torch.empty(M, D, device=dev); dxb = torch.empty(M, D, dtype=BF16, device=dev)
+    dg = torch.empty(D, device=dev); db = torch.empty(D, device=dev)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, resid, dx, dxb, dg, db)
+    assert (dx - (xr.grad + resid)).abs().max().item() < 5e-5
+    assert rel_err(dxb, xr.grad + resid) < 4e-3
+    assert rel_err(dg, gr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
+    # bf16 dy, no residual
+    dyb = dy.to(BF16)
+    xr.grad = None
+    torch.nn.functional.layer_norm(xr, (D,), gamma, beta, 1e-6).backward(dyb.float())
+    ops.layernorm_bwd(dyb, x, gamma, mean, rstd, None, dx, None, dg, db)
+    assert (dx - xr.grad).abs().max().item() < 5e-5
+
+
+# ------------------------------------------------------------------------------ RoPE / patch gather / casts
+@pytest.mark.parametrize("grid,B", [((2, 2, 2), 2), ((8, 14, 14), 1), ((8, 16, 16), 2)])
+def test_rope(ops, dev, grid, B):
+    N = grid[0] * grid[1] * grid[2]
+    qkv = rnd((B * N, 3072), dev, 19, dtype=BF16)
+    tables = ops.rope_tables_device(R.rope_inv_freq(256), R.rope_inv_freq(384), R.rope_inv_freq(384), grid, 0.6, dev)
+    orig = qkv.clone()
+    ops.rope3d_qk_(qkv, tables, grid)
+    x = orig.float().cpu().reshape(B, N, 3072)
+    ref_q = R.rope_rotate(x[..., :1024], *grid)
+    ref_k = R.rope_rotate(x[..., 1024:2048], *grid)
+    got = qkv.float().cpu().reshape(B, N, 3072)
+    assert (got[..., :1024] - ref_q).abs().max().item() < 0.04      # one bf16 rounding of |v| < 6
+    assert (got[..., 1024:2048] - ref_k).abs().max().item() < 0.04
+    assert rel_err(got[..., :2048], torch.cat([ref_q, ref_k], -1)) < 3e-3
+    assert torch.equal(got[..., 2048:], x[..., 2048:])              # V untouched
+    ops.rope3d_qk_(qkv, tables, grid, inverse=True)                   # rotation by -theta undoes it
+    assert rel_err(qkv, orig) < 6e-3
+
+
+def test_tubelet_gather(ops, dev):
+    video = rnd((2, 3, 4, 48, 32), dev, 20)
+    patches = ops.tubelet_gather(video, (2, 16, 16))
+    ref = R.tubelet_patches(video.cpu()).reshape(-1, 1536).to(BF16)
+    assert torch.equal(patches.cpu(), ref)
+
+
+def test_casts(ops, dev):
+    w = rnd((1024, 4096), dev, 21)
+    assert torch.equal(ops.cast_bf16(w), w.to(BF16))
+    assert torch.equal(ops.cast_transpose_bf16(w), w.t().contiguous().to(BF16))
+    v = rnd((1003,), dev, 22)
+    buf = torch.empty(1008, dtype=BF16, device=dev)[:1003]
+    assert torch.equal(ops.cast_bf16(v, buf), v.to(BF16))
+
+
+# ------------------------------------------------------------------------------ masking / JEPA pieces
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_future_mask_bit_exact(ops, dev, dtype):
+    for Tp, ratio in ((4, 0.5), (5, 0.5), (8, 0.75), (8, 0.9), (32, 0.5)):
+        x = rnd((3, Tp * 6, 1024), dev, 23).to(dtype)
+        ref_m, ref_mask = R.future_masking(x.cpu().float(), Tp, ratio)
+        cutoff = int(Tp * (1 - ratio))
+        out, mask = ops.future_mask(x, cutoff * 6)
+        assert torch.equal(mask.cpu(), ref_mask)
+        assert torch.equal(out.cpu().float(), ref_m)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_token_gather_scatter_bit_exact(ops, dev, dtype):
+    B, grid, D = 4, (8, 16, 16), 1024
+    N = 2048
+    ctx, tgt = R.jepa_block_masks(11, B, grid)
+    x = rnd((B, N, D), dev, 24).to(dtype)
+    for idx in (ctx, tgt):
+        g = ops.token_gather(x, idx.to(dev))
+        assert torch.equal(g.cpu(), R.token_gather(x.cpu(), idx))
+        s = ops.token_scatter(g, idx.to(dev), N)
+        assert torch.equal(s.cpu(), R.token_scatter(g.cpu(), idx, N))
+
+
+def test_ema_and_l1(ops, dev):
+    n = 3_000_003
+    tgt = rnd((n,), dev, 25); onl = rnd((n,), dev, 26)
+    ref = R.ema_update(tgt.clone(), onl, 0.996)
+    shadow = torch.empty(n + 5, dtype=BF16, device=dev)[:n]
+    ops.ema_update_(tgt, onl, 0.996, shadow)
+    assert (tgt - ref).abs().max().item() < 1e-6
+    assert torch.equal(shadow, tgt.to(BF16))
+    for dtype in (F32, BF16):
+        p = rnd((7, 333, 1024), dev, 27).to(dtype); t = rnd((7, 333, 1024), dev, 28).to(dtype)
+        loss, grad = ops.l1_loss(p, t)
+        rl, rg = R.l1_latent_loss(p.float().cpu(), t.float().cpu())
+        assert abs(loss.item() - rl.item()) < 1e-5 * max(1.0, rl.item())
+        assert torch.equal(grad.float().cpu(), rg.to(dtype).float())

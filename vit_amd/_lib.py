@@ -1,0 +1,68 @@
+"""ctypes binding of libvit_amd.so (the C ABI declared in include/vit_amd.h).
+
+There is no fallback: if the shared library is missing, `load()` raises, and every op in
+`vit_amd.ops` goes through `load()`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvit_amd.so")
+
+_lib = None
+
+i64, vp, ci, cf = c_int64, c_void_p, c_int, c_float
+
+# name -> (restype, argtypes); mirrors include/vit_amd.h one to one
+SIGNATURES = {
+    "va_version": (ci, []),
+    "va_last_error": (c_char_p, []),
+    "va_gemm_nt": (ci, [vp, vp, i64, i64, i64, i64, i64, ci, vp, vp, vp, vp, vp, i64, ci, vp]),
+    "va_gemm_tn_accum": (ci, [vp, vp, i64, i64, i64, i64, i64, vp, i64, ci, vp]),
+    "va_colsum_bf16_accum": (ci, [vp, i64, i64, i64, vp, vp]),
+    "va_tubelet_gather": (ci, [vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp]),
+    "va_layernorm_fwd": (ci, [vp, vp, vp, vp, ci, vp, vp, i64, i64, cf, vp]),
+    "va_layernorm_bwd_partial_rows": (i64, [i64]),
+    "va_layernorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
+    "va_rope3d_qk_inplace": (ci, [vp, vp, i64, i64, i64, i64, ci, vp]),
+    "va_attn_fwd": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp]),
+    "va_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
+    "va_cast_f32_bf16": (ci, [vp, vp, i64, vp]),
+    "va_cast_transpose_f32_bf16": (ci, [vp, vp, i64, i64, vp]),
+    "va_future_mask": (ci, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "va_token_gather": (ci, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    "va_token_scatter": (ci, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    "va_ema_update": (ci, [vp, vp, vp, i64, cf, vp]),
+    "va_l1_loss": (ci, [vp, vp, ci, vp, vp, ci, cf, i64, vp]),
+}
+
+
+class VitAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raise loudly when it is absent (no CPU or eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitAmdError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). vit_amd has no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().va_last_error().decode(errors="replace")
+        raise VitAmdError(f"{what} failed ({code}): {msg}")

@@ -1,0 +1,108 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libvit_amd.
+// Wavefront = 64 lanes.  bf16 data is carried as raw 16-bit words (`bf16_t`).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vit_amd.h"
+
+typedef uint16_t bf16_t;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;     // one ds_read_b64_tr_b16 result
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define VA_DEVINL __device__ __forceinline__
+
+// ---- bf16 <-> f32 -------------------------------------------------------
+VA_DEVINL float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// Round-to-nearest-even through the compiler's own conversion (keeps NaN a NaN).
+VA_DEVINL bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+VA_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- LDS / global helpers ----------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// Asynchronous 16-byte-per-lane global -> LDS copy.  `lds_wave_base` must be wave-uniform; lane l
+// lands at lds_wave_base + 16*l.  The global source address is per lane.
+VA_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// Transposed LDS read: within each group of 16 lanes a 4-row x 16-column block of 16-bit words is
+// delivered column-major (lane i of the group receives column i, row q in element q).  Lane 4q+p of the
+// group supplies the address of row q, columns 4p..4p+3 (8-byte aligned).  EXEC must be all ones.
+VA_DEVINL s16x4_t lds_read_tr16(const void* lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)lds_addr);
+}
+
+VA_DEVINL bf16x8_t join_tr(s16x4_t lo, s16x4_t hi) {
+    s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+VA_DEVINL f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+VA_DEVINL f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+VA_DEVINL void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Row of accumulator register i in lane-half h for a 32x32 MFMA result.
+VA_DEVINL int acc32_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// Exact-erf GELU and its derivative.
+VA_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+VA_DEVINL float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// Map a launch-order block id onto a work id so that the blocks that share an XCD (ids equal mod 8)
+// receive one contiguous run of work ids: neighbouring tiles then reuse each other's operand panels
+// in that XCD's L2.  Bijective for every block count.
+VA_DEVINL int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// ---- host side ------------------------------------------------------------
+#define VA_OK 0
+#define VA_ERR_INVALID VA_ERR_INVALID_ARG
+#define VA_ERR_LAUNCH VA_ERR_LAUNCH_FAILED
+#define VA_ERR_UNSUPPORTED VA_ERR_UNSUPPORTED_SHAPE
+#ifdef __cplusplus
+extern "C" void va_set_error(const char* fmt, ...);
+#endif
+
+#define VA_CHECK_ARG(cond, ...)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            va_set_error(__VA_ARGS__);         \
+            return VA_ERR_INVALID;             \
+        }                                      \
+    } while (0)
+
+#define VA_CHECK_LAUNCH(name)                                                     \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            va_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+            return VA_ERR_LAUNCH;                                                 \
+        }                                                                         \
+    } while (0)
+

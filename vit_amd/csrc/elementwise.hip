@@ -1,0 +1,577 @@
+// HBM-bound kernels of the encoder path: LayerNorm forward/backward, 3D-RoPE rotation, tubelet patch
+// gather, parameter casts, bias-gradient column sums, token masking / gather / scatter, EMA update and
+// the L1 latent loss.  All of them move 16 bytes per lane per access and keep no state.
+#include "common.h"
+
+namespace {
+
+VA_DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+VA_DEVINL void unpack8(const u32x4_t& v, float* f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = __uint_as_float(v[j] << 16);
+        f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+    }
+}
+VA_DEVINL u32x4_t pack8(const float* f) {
+    return (u32x4_t){pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over rows of D = 1024 f32: one wave per row, 16 elements per lane (4 x float4, stride 256).
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_D = 1024;
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, void* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * LN_D;
+    f32x4_t v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        v[g] = *(const f32x4_t*)(xr + g * 256 + lane * 4);
+        s += v[g][0] + v[g][1] + v[g][2] + v[g][3];
+    }
+    const float mu = wave_sum(s) * (1.0f / LN_D);
+    float ss = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[g][j] - mu;
+            ss += d * d;
+        }
+    const float rs = rsqrtf(wave_sum(ss) * (1.0f / LN_D) + eps);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = g * 256 + lane * 4;
+        const f32x4_t gm = *(const f32x4_t*)(gamma + c);
+        const f32x4_t bt = *(const f32x4_t*)(beta + c);
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[g][j] - mu) * rs * gm[j] + bt[j];
+        if (OUT_BF16) {
+            *(u32x2_t*)((bf16_t*)y + row * LN_D + c) = (u32x2_t){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        } else {
+            *(f32x4_t*)((float*)y + row * LN_D + c) = (f32x4_t){o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
+constexpr int LN_BWD_BLOCKS = 1024;   // upper bound on the number of partial rows
+
+// Each wave walks rows wave_id, wave_id + n_waves, ...; dgamma/dbeta partial sums stay in registers,
+// are combined across the 4 waves of the block through LDS and written as one partial row per block.
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const float* __restrict__ resid_grad, float* __restrict__ dx_out,
+                                                     bf16_t* __restrict__ dx_bf16, float* __restrict__ partial,
+                                                     int64_t M) {
+    __shared__ float red[2][4][LN_D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4_t gm[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gm[g] = *(const f32x4_t*)(gamma + g * 256 + lane * 4);
+    float dg[16], db[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[16], dyv[16];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = g * 256 + lane * 4;
+            const f32x4_t xv = *(const f32x4_t*)(x + row * LN_D + c);
+            float d4[4];
+            if (DY_BF16) {
+                const u32x2_t pk = *(const u32x2_t*)((const bf16_t*)dy + row * LN_D + c);
+                d4[0] = __uint_as_float(pk[0] << 16); d4[1] = __uint_as_float(pk[0] & 0xffff0000u);
+                d4[2] = __uint_as_float(pk[1] << 16); d4[3] = __uint_as_float(pk[1] & 0xffff0000u);
+            } else {
+                const f32x4_t dv = *(const f32x4_t*)((const float*)dy + row * LN_D + c);
+                d4[0] = dv[0]; d4[1] = dv[1]; d4[2] = dv[2]; d4[3] = dv[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float h = (xv[j] - mu) * rs;
+                xh[4 * g + j] = h;
+                dyv[4 * g + j] = d4[j];
+                dg[4 * g + j] += d4[j] * h;
+                db[4 * g + j] += d4[j];
+                const float t = d4[j] * gm[g][j];
+                s1 += t;
+                s2 += t * h;
+            }
+        }
+        s1 = wave_sum(s1) * (1.0f / LN_D);
+        s2 = wave_sum(s2) * (1.0f / LN_D);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = g * 256 + lane * 4;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rs * (dyv[4 * g + j] * gm[g][j] - s1 - xh[4 * g + j] * s2);
+            if (resid_grad != nullptr) {
+                const f32x4_t r = *(const f32x4_t*)(resid_grad + row * LN_D + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += r[j];
+            }
+            *(f32x4_t*)(dx_out + row * LN_D + c) = (f32x4_t){o[0], o[1], o[2], o[3]};
+            if (dx_bf16 != nullptr)
+                *(u32x2_t*)(dx_bf16 + row * LN_D + c) = (u32x2_t){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[0][wave][g * 256 + lane * 4 + j] = dg[4 * g + j];
+            red[1][wave][g * 256 + lane * 4 + j] = db[4 * g + j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < LN_D; c += 256) {
+        partial[((int64_t)blockIdx.x * 2 + 0) * LN_D + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        partial[((int64_t)blockIdx.x * 2 + 1) * LN_D + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    }
+}
+
+// dgamma[c] = sum_b partial[b][0][c], dbeta[c] = sum_b partial[b][1][c]; block = 256 threads = 64 columns x 4.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float a = 0.f, b = 0.f;
+    for (int r = part; r < nblk; r += 4) {
+        a += partial[((int64_t)r * 2 + 0) * LN_D + c];
+        b += partial[((int64_t)r * 2 + 1) * LN_D + c];
+    }
+    red[0][part][threadIdx.x & 63] = a;
+    red[1][part][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (part == 0) {
+        const int i = threadIdx.x;
+        dgamma[c] = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
+        dbeta[c] = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3D RoPE on the Q and K thirds of a packed [M, 3072] bf16 buffer, in place.
+// One wave per (row, q|k): 512 rotation pairs, 8 per lane.  Pair index pi in [0,512): segment t for
+// pi<128 (columns pi, pi+128), h for pi<320 (256+j, 448+j), w else (640+j, 832+j).
+// tables: cos [Tp*128 | Hp*192 | Wp*192] then sin with the same layout.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ tables,
+                                                   int64_t M, int Tp, int Hp, int Wp, float sin_sign) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 2 + (wave >> 1);
+    if (row >= M) return;
+    const int which = wave & 1;   // 0 = Q, 1 = K
+    const int n = (int)(row % ((int64_t)Tp * Hp * Wp));
+    const int t = n / (Hp * Wp), hh = (n / Wp) % Hp, w = n % Wp;
+    const int tab_sz = Tp * 128 + Hp * 192 + Wp * 192;
+    const int pi = lane * 8;
+    int col_a, half, toff;
+    if (pi < 128) { col_a = pi; half = 128; toff = t * 128 + pi; }
+    else if (pi < 320) { col_a = 256 + (pi - 128); half = 192; toff = Tp * 128 + hh * 192 + (pi - 128); }
+    else { col_a = 640 + (pi - 320); half = 192; toff = Tp * 128 + Hp * 192 + w * 192 + (pi - 320); }
+    bf16_t* base = qkv + row * 3072 + which * 1024;
+    float a[8], b[8], c[8], s[8];
+    unpack8(*(const u32x4_t*)(base + col_a), a);
+    unpack8(*(const u32x4_t*)(base + col_a + half), b);
+    *(f32x4_t*)(c) = *(const f32x4_t*)(tables + toff);
+    *(f32x4_t*)(c + 4) = *(const f32x4_t*)(tables + toff + 4);
+    *(f32x4_t*)(s) = *(const f32x4_t*)(tables + tab_sz + toff);
+    *(f32x4_t*)(s + 4) = *(const f32x4_t*)(tables + tab_sz + toff + 4);
+    float oa[8], ob[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float sn = s[j] * sin_sign;
+        oa[j] = a[j] * c[j] - b[j] * sn;
+        ob[j] = b[j] * c[j] + a[j] * sn;
+    }
+    *(u32x4_t*)(base + col_a) = pack8(oa);
+    *(u32x4_t*)(base + col_a + half) = pack8(ob);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tubelet gather: one thread per 8 consecutive pixels of a patch row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tubelet_gather_kernel(const float* __restrict__ video,
+                                                             bf16_t* __restrict__ patches, int64_t total_chunks, int C,
+                                                             int T, int H, int W, int tt, int th, int tw) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_chunks) return;
+    const int Tp = T / tt, Hp = H / th, Wp = W / tw;
+    const int kdim = C * tt * th * tw, cpr = kdim / 8;
+    const int64_t token = gid / cpr;
+    const int col = (int)(gid % cpr) * 8;
+    const int dw = col % tw, dh = (col / tw) % th, dt = (col / (tw * th)) % tt, c = col / (tw * th * tt);
+    const int ntok = Tp * Hp * Wp;
+    const int64_t b = token / ntok;
+    const int n = (int)(token % ntok);
+    const int tp = n / (Hp * Wp), hp = (n / Wp) % Hp, wp = n % Wp;
+    const float* src = video + ((((b * C + c) * T + (tp * tt + dt)) * H + (hp * th + dh)) * (int64_t)W + wp * tw + dw);
+    float f[8];
+    *(f32x4_t*)(f) = *(const f32x4_t*)(src);
+    *(f32x4_t*)(f + 4) = *(const f32x4_t*)(src + 4);
+    *(u32x4_t*)(patches + token * kdim + col) = pack8(f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// casts
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        float f[8];
+        *(f32x4_t*)(f) = *(const f32x4_t*)(src + i);
+        *(f32x4_t*)(f + 4) = *(const f32x4_t*)(src + i + 4);
+        *(u32x4_t*)(dst + i) = pack8(f);
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+    }
+}
+
+// w[R,C] f32 -> wt[C,R] bf16 through a padded 32x32 LDS tile; block (32, 8).
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int R,
+                                                             int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[ty + 8 * j][tx] = w[(int64_t)(r0 + ty + 8 * j) * C + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wt[(int64_t)(c0 + ty + 8 * j) * R + r0 + tx] = f32_to_bf16(tile[tx][ty + 8 * j]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums of a bf16 matrix (bias gradients): block = 64 column groups (8 cols each) x 4 row lanes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ y, int64_t M, int N, int64_t ldy,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4][64][8];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + cg * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (col < N) {
+        for (int64_t r = (int64_t)blockIdx.y * 4 + rl; r < M; r += (int64_t)gridDim.y * 4) {
+            float f[8];
+            unpack8(*(const u32x4_t*)(y + r * ldy + col), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][cg][j] = acc[j];
+    __syncthreads();
+    if (rl == 0 && col < N) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            unsafeAtomicAdd(out + col + j, red[0][cg][j] + red[1][cg][j] + red[2][cg][j] + red[3][cg][j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// token masking / gather / scatter: rows are opaque byte strings moved 16 bytes per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void future_mask_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ out,
+                                                          uint8_t* __restrict__ mask, int64_t rows, int N,
+                                                          int chunks_per_row, int first_masked) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows * chunks_per_row) return;
+    const int64_t row = gid / chunks_per_row;
+    const bool masked = (int)(row % N) >= first_masked;
+    out[gid] = masked ? (u32x4_t){0u, 0u, 0u, 0u} : x[gid];
+    if (gid % chunks_per_row == 0) mask[row] = masked ? 1 : 0;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void token_move_kernel(const u32x4_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                                         u32x4_t* __restrict__ dst, int64_t total_rows, int n_keep,
+                                                         int n_full, int chunks_per_row) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_rows * chunks_per_row) return;
+    const int64_t r = gid / chunks_per_row;           // row in the compact (B, n_keep) space
+    const int c = (int)(gid % chunks_per_row);
+    const int64_t b = r / n_keep;
+    const int64_t full_row = b * n_full + idx[r];
+    if (SCATTER) dst[full_row * chunks_per_row + c] = src[gid];
+    else dst[gid] = src[full_row * chunks_per_row + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// EMA and L1
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tgt, const float* __restrict__ onl,
+                                                  bf16_t* __restrict__ shadow, int64_t n, float m) {
+    const float om = 1.0f - m;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const f32x4_t t = *(const f32x4_t*)(tgt + i);
+            const f32x4_t o = *(const f32x4_t*)(onl + i);
+            const f32x4_t r = {m * t[0] + om * o[0], m * t[1] + om * o[1], m * t[2] + om * o[2], m * t[3] + om * o[3]};
+            *(f32x4_t*)(tgt + i) = r;
+            if (shadow) *(u32x2_t*)(shadow + i) = (u32x2_t){pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+        } else {
+            for (int64_t j = i; j < n; ++j) {
+                const float r = m * tgt[j] + om * onl[j];
+                tgt[j] = r;
+                if (shadow) shadow[j] = f32_to_bf16(r);
+            }
+        }
+    }
+}
+
+template <bool IN_BF16, bool GRAD_BF16>
+__global__ __launch_bounds__(256) void l1_kernel(const void* __restrict__ pred, const void* __restrict__ tgt,
+                                                 float* __restrict__ loss_sum, void* __restrict__ grad, float gscale,
+                                                 int64_t n) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 2048) {
+        float p[8], t[8], g[8];
+        const int cnt = (n - i) >= 8 ? 8 : (int)(n - i);
+        if (cnt == 8) {
+            if (IN_BF16) {
+                unpack8(*(const u32x4_t*)((const bf16_t*)pred + i), p);
+                unpack8(*(const u32x4_t*)((const bf16_t*)tgt + i), t);
+            } else {
+                *(f32x4_t*)(p) = *(const f32x4_t*)((const float*)pred + i);
+                *(f32x4_t*)(p + 4) = *(const f32x4_t*)((const float*)pred + i + 4);
+                *(f32x4_t*)(t) = *(const f32x4_t*)((const float*)tgt + i);
+                *(f32x4_t*)(t + 4) = *(const f32x4_t*)((const float*)tgt + i + 4);
+            }
+        } else {
+            for (int j = 0; j < 8; ++j) {
+                p[j] = 0.f;
+                t[j] = 0.f;
+                if (j < cnt) {
+                    p[j] = IN_BF16 ? bf16_to_f32(((const bf16_t*)pred)[i + j]) : ((const float*)pred)[i + j];
+                    t[j] = IN_BF16 ? bf16_to_f32(((const bf16_t*)tgt)[i + j]) : ((const float*)tgt)[i + j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = p[j] - t[j];
+            acc += fabsf(d);
+            g[j] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+        }
+        if (grad != nullptr) {
+            if (cnt == 8) {
+                if (GRAD_BF16) *(u32x4_t*)((bf16_t*)grad + i) = pack8(g);
+                else {
+                    *(f32x4_t*)((float*)grad + i) = *(f32x4_t*)(g);
+                    *(f32x4_t*)((float*)grad + i + 4) = *(f32x4_t*)(g + 4);
+                }
+            } else {
+                for (int j = 0; j < cnt; ++j) {
+                    if (GRAD_BF16) ((bf16_t*)grad)[i + j] = f32_to_bf16(g[j]);
+                    else ((float*)grad)[i + j] = g[j];
+                }
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+inline unsigned blocks_for(int64_t items, int per_block) { return (unsigned)((items + per_block - 1) / per_block); }
+
+}  // namespace
+
+// ===================================================================================================
+extern "C" int va_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
+                                float* mean, float* rstd, int64_t M, int64_t D, float eps, hipStream_t stream) {
+    VA_CHECK_ARG(x && gamma && beta && y && mean && rstd, "va_layernorm_fwd: null operand");
+    VA_CHECK_ARG(D == LN_D, "va_layernorm_fwd: width %lld not supported (the encoder is 1024 wide)", (long long)D);
+    VA_CHECK_ARG(M > 0, "va_layernorm_fwd: empty input");
+    VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, "va_layernorm_fwd: misaligned operand");
+    if (out_bf16)
+        hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, M, eps);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, M, eps);
+    VA_CHECK_LAUNCH("va_layernorm_fwd");
+    return VA_OK;
+}
+
+extern "C" int64_t va_layernorm_bwd_partial_rows(int64_t M) {
+    const int64_t need = (M + 3) / 4;
+    return need < LN_BWD_BLOCKS ? need : LN_BWD_BLOCKS;
+}
+
+extern "C" int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16,
+                                float* partial, float* dgamma, float* dbeta, int64_t M, int64_t D, hipStream_t stream) {
+    VA_CHECK_ARG(dy && x && gamma && mean && rstd && dx_out && partial && dgamma && dbeta, "va_layernorm_bwd: null operand");
+    VA_CHECK_ARG(D == LN_D, "va_layernorm_bwd: width %lld not supported (the encoder is 1024 wide)", (long long)D);
+    VA_CHECK_ARG(M > 0, "va_layernorm_bwd: empty input");
+    VA_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx_out | (uintptr_t)gamma) % 16 == 0, "va_layernorm_bwd: misaligned operand");
+    const int nblk = (int)va_layernorm_bwd_partial_rows(M);
+    if (dy_bf16)
+        hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, dy, x, gamma, mean, rstd, resid_grad,
+                           dx_out, (bf16_t*)dx_bf16, partial, M);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, dy, x, gamma, mean, rstd, resid_grad,
+                           dx_out, (bf16_t*)dx_bf16, partial, M);
+    VA_CHECK_LAUNCH("va_layernorm_bwd");
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(LN_D / 64), dim3(256), 0, stream, partial, nblk, dgamma, dbeta);
+    VA_CHECK_LAUNCH("va_layernorm_bwd(reduce)");
+    return VA_OK;
+}
+
+extern "C" int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, int64_t Tp, int64_t Hp, int64_t Wp,
+                                    int inverse, hipStream_t stream) {
+    VA_CHECK_ARG(qkv && tables, "va_rope3d_qk_inplace: null operand");
+    VA_CHECK_ARG(M > 0 && Tp > 0 && Hp > 0 && Wp > 0, "va_rope3d_qk_inplace: empty input");
+    VA_CHECK_ARG(M % (Tp * Hp * Wp) == 0, "va_rope3d_qk_inplace: M=%lld is not a whole number of clips of %lld tokens",
+                 (long long)M, (long long)(Tp * Hp * Wp));
+    VA_CHECK_ARG(((uintptr_t)qkv | (uintptr_t)tables) % 16 == 0, "va_rope3d_qk_inplace: misaligned operand");
+    hipLaunchKernelGGL(rope_kernel, dim3(blocks_for(M, 2)), dim3(256), 0, stream, (bf16_t*)qkv, tables, M, (int)Tp,
+                       (int)Hp, (int)Wp, inverse ? -1.0f : 1.0f);
+    VA_CHECK_LAUNCH("va_rope3d_qk_inplace");
+    return VA_OK;
+}
+
+extern "C" int va_tubelet_gather(const float* video, void* patches, int64_t B, int64_t C, int64_t T, int64_t H,
+                                 int64_t W, int64_t tt, int64_t th, int64_t tw, hipStream_t stream) {
+    VA_CHECK_ARG(video && patches, "va_tubelet_gather: null operand");
+    VA_CHECK_ARG(B > 0 && C > 0 && tt > 0 && th > 0 && tw > 0 && T >= tt && H >= th && W >= tw, "va_tubelet_gather: bad shape");
+    VA_CHECK_ARG(tw % 8 == 0 && W % 4 == 0, "va_tubelet_gather: tubelet width must be a multiple of 8 and W of 4");
+    VA_CHECK_ARG(((uintptr_t)video | (uintptr_t)patches) % 16 == 0, "va_tubelet_gather: misaligned operand");
+    const int64_t tokens = B * (T / tt) * (H / th) * (W / tw);
+    const int64_t chunks = tokens * (C * tt * th * tw / 8);
+    hipLaunchKernelGGL(tubelet_gather_kernel, dim3(blocks_for(chunks, 256)), dim3(256), 0, stream, video,
+                       (bf16_t*)patches, chunks, (int)C, (int)T, (int)H, (int)W, (int)tt, (int)th, (int)tw);
+    VA_CHECK_LAUNCH("va_tubelet_gather");
+    return VA_OK;
+}
+
+extern "C" int va_cast_f32_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
+    VA_CHECK_ARG(src && dst && n > 0, "va_cast_f32_bf16: null or empty operand");
+    VA_CHECK_ARG(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "va_cast_f32_bf16: misaligned operand");
+    hipLaunchKernelGGL(cast_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+    VA_CHECK_LAUNCH("va_cast_f32_bf16");
+    return VA_OK;
+}
+
+extern "C" int va_cast_transpose_f32_bf16(const float* w, void* wt, int64_t R, int64_t C, hipStream_t stream) {
+    VA_CHECK_ARG(w && wt, "va_cast_transpose_f32_bf16: null operand");
+    VA_CHECK_ARG(R > 0 && C > 0 && R % 32 == 0 && C % 32 == 0, "va_cast_transpose_f32_bf16: R and C must be multiples of 32");
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)(C / 32), (unsigned)(R / 32)), dim3(256), 0, stream, w,
+                       (bf16_t*)wt, (int)R, (int)C);
+    VA_CHECK_LAUNCH("va_cast_transpose_f32_bf16");
+    return VA_OK;
+}
+
+extern "C" int va_colsum_bf16_accum(const void* y, int64_t M, int64_t N, int64_t ldy, float* out, hipStream_t stream) {
+    VA_CHECK_ARG(y && out, "va_colsum_bf16_accum: null operand");
+    VA_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && ldy % 8 == 0 && ldy >= N, "va_colsum_bf16_accum: bad shape");
+    VA_CHECK_ARG((uintptr_t)y % 16 == 0, "va_colsum_bf16_accum: misaligned operand");
+    int64_t gy = (M + 255) / 256;
+    if (gy > 128) gy = 128;
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(N, 512), (unsigned)gy), dim3(256), 0, stream, (const bf16_t*)y, M,
+                       (int)N, ldy, out);
+    VA_CHECK_LAUNCH("va_colsum_bf16_accum");
+    return VA_OK;
+}
+
+extern "C" int va_future_mask(const void* x, void* out, uint8_t* mask, int64_t B, int64_t N, int64_t D,
+                              int64_t elem_bytes, int64_t first_masked_row, hipStream_t stream) {
+    VA_CHECK_ARG(x && out && mask, "va_future_mask: null operand");
+    VA_CHECK_ARG(B > 0 && N > 0 && D > 0 && (elem_bytes == 2 || elem_bytes == 4), "va_future_mask: bad shape");
+    VA_CHECK_ARG((D * elem_bytes) % 16 == 0, "va_future_mask: rows must be a multiple of 16 bytes");
+    VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)out) % 16 == 0, "va_future_mask: misaligned operand");
+    VA_CHECK_ARG(first_masked_row >= 0, "va_future_mask: negative cut-off");
+    const int cpr = (int)(D * elem_bytes / 16);
+    hipLaunchKernelGGL(future_mask_kernel, dim3(blocks_for(B * N * cpr, 256)), dim3(256), 0, stream, (const u32x4_t*)x,
+                       (u32x4_t*)out, mask, B * N, (int)N, cpr, (int)(first_masked_row > N ? N : first_masked_row));
+    VA_CHECK_LAUNCH("va_future_mask");
+    return VA_OK;
+}
+
+static int token_move(bool scatter, const void* src, const int32_t* idx, void* dst, int64_t B, int64_t n_full,
+                      int64_t n_keep, int64_t row_bytes, hipStream_t stream, const char* who) {
+    VA_CHECK_ARG(src && idx && dst, "%s: null operand", who);
+    VA_CHECK_ARG(B > 0 && n_full > 0 && n_keep > 0 && n_keep <= n_full, "%s: bad shape", who);
+    VA_CHECK_ARG(row_bytes > 0 && row_bytes % 16 == 0, "%s: rows must be a multiple of 16 bytes", who);
+    VA_CHECK_ARG(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "%s: misaligned operand", who);
+    const int cpr = (int)(row_bytes / 16);
+    if (scatter) {
+        if (hipMemsetAsync(dst, 0, (size_t)(B * n_full * row_bytes), stream) != hipSuccess) {
+            va_set_error("%s: memset failed", who);
+            return VA_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(token_move_kernel<true>, dim3(blocks_for(B * n_keep * cpr, 256)), dim3(256), 0, stream,
+                           (const u32x4_t*)src, idx, (u32x4_t*)dst, B * n_keep, (int)n_keep, (int)n_full, cpr);
+    } else {
+        hipLaunchKernelGGL(token_move_kernel<false>, dim3(blocks_for(B * n_keep * cpr, 256)), dim3(256), 0, stream,
+                           (const u32x4_t*)src, idx, (u32x4_t*)dst, B * n_keep, (int)n_keep, (int)n_full, cpr);
+    }
+    VA_CHECK_LAUNCH(who);
+    return VA_OK;
+}
+
+extern "C" int va_token_gather(const void* x, const int32_t* idx, void* out, int64_t B, int64_t N_src, int64_t N_keep,
+                               int64_t row_bytes, hipStream_t stream) {
+    return token_move(false, x, idx, out, B, N_src, N_keep, row_bytes, stream, "va_token_gather");
+}
+
+extern "C" int va_token_scatter(const void* src, const int32_t* idx, void* out, int64_t B, int64_t N_dst,
+                                int64_t N_keep, int64_t row_bytes, hipStream_t stream) {
+    return token_move(true, src, idx, out, B, N_dst, N_keep, row_bytes, stream, "va_token_scatter");
+}
+
+extern "C" int va_ema_update(float* target, const float* online, void* target_bf16, int64_t n, float momentum,
+                             hipStream_t stream) {
+    VA_CHECK_ARG(target && online && n > 0, "va_ema_update: null or empty operand");
+    VA_CHECK_ARG(((uintptr_t)target | (uintptr_t)online | (uintptr_t)target_bf16) % 16 == 0, "va_ema_update: misaligned operand");
+    unsigned blocks = blocks_for(n, 1024);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(ema_kernel, dim3(blocks), dim3(256), 0, stream, target, online, (bf16_t*)target_bf16, n, momentum);
+    VA_CHECK_LAUNCH("va_ema_update");
+    return VA_OK;
+}
+
+extern "C" int va_l1_loss(const void* pred, const void* target, int in_bf16, float* loss_sum, void* grad,
+                          int grad_bf16, float grad_scale, int64_t n, hipStream_t stream) {
+    VA_CHECK_ARG(pred && target && loss_sum && n > 0, "va_l1_loss: null or empty operand");
+    VA_CHECK_ARG(((uintptr_t)pred | (uintptr_t)target | (uintptr_t)grad) % 16 == 0, "va_l1_loss: misaligned operand");
+    if (hipMemsetAsync(loss_sum, 0, sizeof(float), stream) != hipSuccess) {
+        va_set_error("va_l1_loss: memset failed");
+        return VA_ERR_LAUNCH;
+    }
+    unsigned blocks = blocks_for(n, 2048);
+    if (blocks > 8192) blocks = 8192;
+#define VA_L1(IB, GB) hipLaunchKernelGGL((l1_kernel<IB, GB>), dim3(blocks), dim3(256), 0, stream, pred, target, loss_sum, grad, grad_scale, n)
+    if (in_bf16) { if (grad_bf16) VA_L1(true, true); else VA_L1(true, false); }
+    else { if (grad_bf16) VA_L1(false, true); else VA_L1(false, false); }
+#undef VA_L1
+    VA_CHECK_LAUNCH("va_l1_loss");
+    return VA_OK;
+}

@@ -1,0 +1,195 @@
+// Weight-gradient GEMM:  dW[N,K] (f32) += dY[M,N]^T * X[M,K],  bf16 operands, contraction over the
+// token dimension M (tens of thousands), which is the SLOW index of both operands in memory.
+//
+// Structure (gfx950):
+//   * workgroup tile 128(n) x 128(k), contraction step 64 rows of M, 4 waves (2x2), each wave a 64x64
+//     sub-tile as 2x2 MFMA 32x32x16 tiles.
+//   * both operand tiles are staged exactly as they lie in memory ([64 m][128 cols], 256-byte rows) with
+//     16-byte direct-to-LDS loads; the MFMA fragments (8 consecutive m for one column) are produced by
+//     the hardware transposing LDS read ds_read_b64_tr_b16, two per fragment.  The 16-byte chunk index
+//     is XORed with ((row&3)<<2) on the load's source address and on the read, which spreads the four
+//     rows of one transposed read over all 64 banks.
+//   * M is split over gridDim.y slices; every slice adds its tile into dW with f32 atomics.  dY^T is
+//     the MFMA A operand, so one accumulator register across a wave is two 128-byte row segments of dW,
+//     the shape at which the memory-side atomic units run at full rate.
+//   * a ragged last M-tile is zero-filled in LDS after it lands (sources are clamped to row M-1).
+#include "common.h"
+
+namespace {
+
+constexpr int TBM = 64;    // contraction rows per step
+constexpr int TBN = 128;   // tile edge (both n and k)
+constexpr int TILE_BYTES = TBM * TBN * 2;     // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
+                                                      int M, int N, int K, int lddy, int ldx, float* __restrict__ DW,
+                                                      int lddw, int m_per_slice) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+
+    const int tiles_k = K / TBN;
+    const int tiles = (N / TBN) * tiles_k;
+    const int id = xcd_remap(blockIdx.x, tiles);
+    const int n0 = (id / tiles_k) * TBN;
+    const int k0 = (id % tiles_k) * TBN;
+    const int m_begin = blockIdx.y * m_per_slice;
+    int m_end = m_begin + m_per_slice;
+    m_end = m_end < M ? m_end : M;
+    if (m_begin >= m_end) return;   // uniform for the whole workgroup
+    const int nsteps = (m_end - m_begin + TBM - 1) / TBM;
+
+    // staging: 1024 chunks of 16 B per operand tile, 4 per thread.  chunk q -> row q>>4, slot q&15.
+    int srow[4], scol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = i * 256 + tid;
+        srow[i] = q >> 4;
+        scol[i] = (((q & 15) ^ ((srow[i] & 3) << 2))) * 8;
+    }
+    auto stage = [&](int buf, int step) {
+        char* yb = smem + buf * STAGE_BYTES;
+        char* xb = yb + TILE_BYTES;
+        const int mb = m_begin + step * TBM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = mb + srow[i];
+            m = m < M ? m : M - 1;
+            glds16(DY + (size_t)m * lddy + n0 + scol[i], yb + (i * 256 + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = mb + srow[i];
+            m = m < M ? m : M - 1;
+            glds16(X + (size_t)m * ldx + k0 + scol[i], xb + (i * 256 + wave * 64) * 16);
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    // transposed-read lane roles: 16-lane group gi = lane>>4: column half cg = gi&1, k half h = gi>>1;
+    // inside the group lane 4q+p addresses row q, columns 4p..4p+3.
+    const int gi = lane >> 4, cg = gi & 1, h = gi >> 1, q = (lane & 15) >> 2, p = lane & 3;
+    // byte offset inside a tile for k-step 0, column tile 0 of this wave; row r0 = 8h + q
+    auto tr_off = [&](int colbase) {
+        const int row = 8 * h + q;
+        const int chunk = ((colbase + 16 * cg + 4 * p) >> 3) ^ ((row & 3) << 2);
+        return row * 256 + (chunk << 4) + (p & 1) * 8;
+    };
+    int yoff[2], xoff[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        yoff[a] = tr_off(wn * 64 + a * 32);
+        xoff[a] = tr_off(wk * 64 + a * 32);
+    }
+
+    auto compute = [&](int buf) {
+        const char* yb = smem + buf * STAGE_BYTES;
+        const char* xb = yb + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {   // 16 rows of m per MFMA k-step
+            bf16x8_t af[2], bfr[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const char* pa = yb + yoff[a] + ks * 16 * 256;
+                af[a] = join_tr(lds_read_tr16(pa), lds_read_tr16(pa + 4 * 256));
+                const char* pb = xb + xoff[a] + ks * 16 * 256;
+                bfr[a] = join_tr(lds_read_tr16(pb), lds_read_tr16(pb + 4 * 256));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(af[a], bfr[b], acc[a][b]);
+        }
+    };
+
+    // zero rows [valid, 64) of both operand tiles of `buf` (ragged tail of M)
+    auto zero_tail = [&](int buf, int valid) {
+        char* base = smem + buf * STAGE_BYTES;
+        for (int c = tid; c < 2 * TBM * 16; c += 256) {
+            const int t = c / (TBM * 16), r = (c / 16) % TBM;
+            if (r >= valid) *(u32x4_t*)(base + t * TILE_BYTES + (c % (TBM * 16)) * 16) = (u32x4_t){0u, 0u, 0u, 0u};
+        }
+    };
+    const int tail_valid = (m_end - m_begin) - (nsteps - 1) * TBM;   // rows valid in the last step (1..64)
+
+    stage(0, 0);
+    wait_vm0();
+    __syncthreads();
+    if (nsteps == 1 && tail_valid < TBM) {
+        zero_tail(0, tail_valid);
+        __syncthreads();
+    }
+    for (int s = 0; s < nsteps - 1; ++s) {
+        stage((s + 1) & 1, s + 1);
+        compute(s & 1);
+        wait_vm0();
+        __syncthreads();
+        if (s + 1 == nsteps - 1 && tail_valid < TBM) {
+            zero_tail((s + 1) & 1, tail_valid);
+            __syncthreads();
+        }
+    }
+    compute((nsteps - 1) & 1);
+
+    // D[row = n][col = k]: lane column = lane&31, register i -> row acc32_row(i, lane>>5)
+    const int hh = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float* base = DW + (size_t)(n0 + wn * 64 + a * 32) * lddw + k0 + wk * 64 + b * 32 + col;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) unsafeAtomicAdd(base + (size_t)acc32_row(i, hh) * lddw, acc[a][b][i]);
+        }
+}
+
+}  // namespace
+
+extern "C" int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_t N, int64_t K, int64_t lddy,
+                                int64_t ldx, float* dw, int64_t lddw, int split_k, hipStream_t stream) {
+    VA_CHECK_ARG(dy && x && dw, "va_gemm_tn_accum: null operand");
+    VA_CHECK_ARG(M > 0 && N > 0 && K > 0, "va_gemm_tn_accum: empty problem");
+    VA_CHECK_ARG(N % 128 == 0 && K % 128 == 0, "va_gemm_tn_accum: N=%lld and K=%lld must be multiples of 128",
+                 (long long)N, (long long)K);
+    VA_CHECK_ARG(lddy >= N && ldx >= K && lddw >= K, "va_gemm_tn_accum: leading dimension smaller than the row length");
+    VA_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0, "va_gemm_tn_accum: leading dimensions must keep 16-byte alignment");
+    VA_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x) % 16 == 0 && (uintptr_t)dw % 4 == 0, "va_gemm_tn_accum: misaligned operand");
+    VA_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "va_gemm_tn_accum: problem too large");
+    const int tiles = (int)((N / 128) * (K / 128));
+    const int steps = (int)((M + TBM - 1) / TBM);
+    if (split_k <= 0) {
+        split_k = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
+        const int max_split = (steps + 7) / 8;          // at least 8 steps per slice
+        if (split_k > max_split) split_k = max_split;
+        if (split_k < 1) split_k = 1;
+    }
+    if (split_k > steps) split_k = steps;
+    const int steps_per = (steps + split_k - 1) / split_k;
+    const int m_per_slice = steps_per * TBM;
+    const int slices = (int)((M + m_per_slice - 1) / m_per_slice);
+
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess) {
+            va_set_error("va_gemm_tn_accum: cannot reserve %d bytes of LDS", 2 * STAGE_BYTES);
+            return VA_ERR_LAUNCH;
+        }
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, slices), dim3(256), 2 * STAGE_BYTES, stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, (int)M, (int)N, (int)K, (int)lddy, (int)ldx, dw, (int)lddw, m_per_slice);
+    VA_CHECK_LAUNCH("va_gemm_tn_accum");
+    return VA_OK;
+}

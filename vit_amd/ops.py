@@ -1,0 +1,289 @@
+"""Tensor-level wrappers over the C ABI: shape/dtype checks on the host, raw pointers and the current
+HIP stream across the boundary.  Nothing here computes; torch is used for memory and streams only."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+EPI_BF16, EPI_BIAS_GELU, EPI_F32, EPI_GELU_BWD = 0, 1, 2, 3
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str, inner_contig: bool = True):
+    if not t.is_cuda:
+        raise _lib.VitAmdError(f"{name}: tensor must live on a HIP device (vit_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if inner_contig and t.dim() >= 1 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+
+
+def _ld(t: torch.Tensor) -> int:
+    """Leading dimension of a 2-D row-major view (rows may be strided)."""
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ------------------------------------------------------------------ GEMMs
+def gemm_nt(x: torch.Tensor, w: torch.Tensor, epilogue: int, out: torch.Tensor, out2: Optional[torch.Tensor] = None,
+            bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+            aux: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+    """out[M,N] = x[M,K] @ w[N,K]^T with a fused epilogue (see include/vit_amd.h)."""
+    _need(x, BF16, "x"); _need(w, BF16, "w")
+    M, K = x.shape
+    N, K2 = w.shape
+    if K2 != K:
+        raise ValueError(f"gemm_nt: K mismatch {K} vs {K2}")
+    _need(out, F32 if epilogue == EPI_F32 else BF16, "out")
+    if tuple(out.shape) != (M, N):
+        raise ValueError(f"gemm_nt: out shape {tuple(out.shape)} != {(M, N)}")
+    ldc = _ld(out)
+    for t, nm, dt in ((out2, "out2", BF16), (aux, "aux", BF16), (resid, "resid", F32)):
+        if t is not None:
+            _need(t, dt, nm)
+            if tuple(t.shape) != (M, N) or _ld(t) != ldc:
+                raise ValueError(f"gemm_nt: {nm} must match out's shape and leading dimension")
+    if bias is not None:
+        _need(bias, F32, "bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise ValueError("gemm_nt: bias must be a contiguous [N] vector")
+    lib = _lib.load()
+    check(lib.va_gemm_nt(_p(x), _p(w), M, N, K, _ld(x), _ld(w), epilogue, _p(out), _p(out2), _p(bias), _p(resid),
+                         _p(aux), ldc, tile, _stream()), "va_gemm_nt")
+    return out
+
+
+def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, split_k: int = 0) -> torch.Tensor:
+    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]."""
+    _need(dy, BF16, "dy"); _need(x, BF16, "x"); _need(dw, F32, "dw")
+    M, N = dy.shape
+    M2, K = x.shape
+    if M2 != M or tuple(dw.shape) != (N, K):
+        raise ValueError(f"gemm_tn_accum: shapes dy{tuple(dy.shape)} x{tuple(x.shape)} dw{tuple(dw.shape)}")
+    lib = _lib.load()
+    check(lib.va_gemm_tn_accum(_p(dy), _p(x), M, N, K, _ld(dy), _ld(x), _p(dw), _ld(dw), split_k, _stream()),
+          "va_gemm_tn_accum")
+    return dw
+
+
+def colsum_accum(y: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _need(y, BF16, "y"); _need(out, F32, "out")
+    M, N = y.shape
+    if out.numel() != N or not out.is_contiguous():
+        raise ValueError("colsum_accum: out must be a contiguous [N] vector")
+    check(_lib.load().va_colsum_bf16_accum(_p(y), M, N, _ld(y), _p(out), _stream()), "va_colsum_bf16_accum")
+    return out
+
+
+# ------------------------------------------------------------------ patch gather
+def tubelet_gather(video: torch.Tensor, tubelet: Tuple[int, int, int], patches: Optional[torch.Tensor] = None):
+    _need(video, F32, "video")
+    if video.dim() != 5 or not video.is_contiguous():
+        raise ValueError("tubelet_gather: video must be a contiguous (B,C,T,H,W) tensor")
+    B, C, T, H, W = video.shape
+    tt, th, tw = tubelet
+    M = B * (T // tt) * (H // th) * (W // tw)
+    Kd = C * tt * th * tw
+    if patches is None:
+        patches = torch.empty(M, Kd, dtype=BF16, device=video.device)
+    _need(patches, BF16, "patches")
+    if tuple(patches.shape) != (M, Kd) or not patches.is_contiguous():
+        raise ValueError("tubelet_gather: bad patches buffer")
+    check(_lib.load().va_tubelet_gather(_p(video), _p(patches), B, C, T, H, W, tt, th, tw, _stream()), "va_tubelet_gather")
+    return patches
+
+
+# ------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, out, mean, rstd, eps: float = 1e-6):
+    _need(x, F32, "x"); _need(gamma, F32, "gamma"); _need(beta, F32, "beta")
+    M, D = x.shape
+    if not (x.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (M, D)):
+        raise ValueError("layernorm_fwd: x/out must be contiguous [M,D]")
+    if out.dtype not in (BF16, F32):
+        raise TypeError("layernorm_fwd: out must be bf16 or f32")
+    _need(mean, F32, "mean"); _need(rstd, F32, "rstd")
+    if mean.numel() != M or rstd.numel() != M:
+        raise ValueError("layernorm_fwd: mean/rstd must have M elements")
+    check(_lib.load().va_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(out), int(out.dtype == BF16), _p(mean), _p(rstd),
+                                       M, D, eps, _stream()), "va_layernorm_fwd")
+    return out
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, dgamma, dbeta):
+    _need(x, F32, "x"); _need(dx_out, F32, "dx_out"); _need(dgamma, F32, "dgamma"); _need(dbeta, F32, "dbeta")
+    M, D = x.shape
+    if dy.dtype not in (BF16, F32) or tuple(dy.shape) != (M, D) or not dy.is_contiguous():
+        raise ValueError("layernorm_bwd: dy must be contiguous [M,D] bf16/f32")
+    for t in (resid_grad, dx_bf16):
+        if t is not None and (tuple(t.shape) != (M, D) or not t.is_contiguous()):
+            raise ValueError("layernorm_bwd: optional tensors must be contiguous [M,D]")
+    if resid_grad is not None:
+        _need(resid_grad, F32, "resid_grad")
+    if dx_bf16 is not None:
+        _need(dx_bf16, BF16, "dx_bf16")
+    lib = _lib.load()
+    rows = lib.va_layernorm_bwd_partial_rows(M)
+    partial = torch.empty(rows * 2 * D, dtype=F32, device=x.device)
+    check(lib.va_layernorm_bwd(_p(dy), int(dy.dtype == BF16), _p(x), _p(gamma), _p(mean), _p(rstd), _p(resid_grad),
+                               _p(dx_out), _p(dx_bf16), _p(partial), _p(dgamma), _p(dbeta), M, D, _stream()),
+          "va_layernorm_bwd")
+    return dx_out
+
+
+# ------------------------------------------------------------------ RoPE
+def rope_tables_device(inv_freq_t, inv_freq_h, inv_freq_w, grid: Tuple[int, int, int], temporal_scale: float,
+                       device) -> torch.Tensor:
+    """Half-width cos|sin tables in the layout va_rope3d_qk_inplace expects.  The angle arithmetic is
+    done in f32 on the host exactly as the reference's VideoRoPE3D.forward does (swm:192-222):
+    position (scaled for t) times inverse frequency, then cos / sin."""
+    Tp, Hp, Wp = grid
+    cos_parts, sin_parts = [], []
+    for n, inv, sc in ((Tp, inv_freq_t, temporal_scale), (Hp, inv_freq_h, 1.0), (Wp, inv_freq_w, 1.0)):
+        pos = torch.arange(n).float() * sc
+        ang = torch.outer(pos, inv.detach().float().cpu())
+        cos_parts.append(ang.cos().reshape(-1))
+        sin_parts.append(ang.sin().reshape(-1))
+    return torch.cat(cos_parts + sin_parts).to(device)
+
+
+def rope3d_qk_(qkv: torch.Tensor, tables: torch.Tensor, grid: Tuple[int, int, int], inverse: bool = False):
+    _need(qkv, BF16, "qkv"); _need(tables, F32, "tables")
+    M, W3 = qkv.shape
+    Tp, Hp, Wp = grid
+    if W3 != 3072 or not qkv.is_contiguous():
+        raise ValueError("rope3d_qk_: qkv must be a contiguous [M, 3072] buffer")
+    if tables.numel() != 2 * (Tp * 128 + Hp * 192 + Wp * 192):
+        raise ValueError("rope3d_qk_: table size does not match the grid")
+    check(_lib.load().va_rope3d_qk_inplace(_p(qkv), _p(tables), M, Tp, Hp, Wp, int(inverse), _stream()),
+          "va_rope3d_qk_inplace")
+    return qkv
+
+
+# ------------------------------------------------------------------ attention
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2: torch.Tensor):
+    """qkv: packed [B*N, 3*D] bf16 (q | k | v thirds); out [B*N, D] bf16; lse2 [B*H, N] f32."""
+    _need(qkv, BF16, "qkv"); _need(out, BF16, "out"); _need(lse2, F32, "lse2")
+    M, W3 = qkv.shape
+    D = W3 // 3
+    if M != B * N or tuple(out.shape) != (M, D) or lse2.numel() != B * H * N or D % H:
+        raise ValueError("attn_fwd: inconsistent shapes")
+    hd = D // H
+    es = qkv.element_size()
+    check(_lib.load().va_attn_fwd(qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out),
+                                  _p(lse2), B, N, H, hd, _ld(qkv), _ld(out), _stream()), "va_attn_fwd")
+    return out
+
+
+def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int):
+    _need(qkv, BF16, "qkv"); _need(out, BF16, "out"); _need(d_out, BF16, "d_out"); _need(dqkv, BF16, "dqkv")
+    M, W3 = qkv.shape
+    D = W3 // 3
+    if tuple(dqkv.shape) != (M, W3) or tuple(d_out.shape) != (M, D) or _ld(d_out) != _ld(out):
+        raise ValueError("attn_bwd: inconsistent shapes")
+    hd = D // H
+    es = 2
+    delta = torch.empty(B * H * N, dtype=F32, device=qkv.device)
+    check(_lib.load().va_attn_bwd(qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out),
+                                  _p(d_out), _p(lse2), _p(delta), dqkv.data_ptr(), dqkv.data_ptr() + D * es,
+                                  dqkv.data_ptr() + 2 * D * es, B, N, H, hd, _ld(qkv), _ld(out), _ld(dqkv), _stream()),
+          "va_attn_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------ casts
+def cast_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need(src, F32, "src")
+    if not src.is_contiguous():
+        raise ValueError("cast_bf16: src must be contiguous")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    check(_lib.load().va_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "va_cast_f32_bf16")
+    return dst
+
+
+def cast_transpose_bf16(w: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need(w, F32, "w")
+    if w.dim() != 2 or not w.is_contiguous():
+        raise ValueError("cast_transpose_bf16: w must be a contiguous matrix")
+    R, C = w.shape
+    if dst is None:
+        dst = torch.empty(C, R, dtype=BF16, device=w.device)
+    check(_lib.load().va_cast_transpose_f32_bf16(_p(w), _p(dst), R, C, _stream()), "va_cast_transpose_f32_bf16")
+    return dst
+
+
+# ------------------------------------------------------------------ masking / JEPA pieces
+def future_mask(x: torch.Tensor, first_masked_row: int):
+    if x.dim() != 3 or not x.is_contiguous() or x.dtype not in (BF16, F32):
+        raise ValueError("future_mask: x must be a contiguous (B,N,D) bf16/f32 tensor")
+    if not x.is_cuda:
+        raise _lib.VitAmdError("future_mask: tensor must live on a HIP device")
+    B, N, D = x.shape
+    out = torch.empty_like(x)
+    mask = torch.empty(B, N, dtype=torch.uint8, device=x.device)
+    check(_lib.load().va_future_mask(_p(x), _p(out), _p(mask), B, N, D, x.element_size(), first_masked_row, _stream()),
+          "va_future_mask")
+    return out, mask.view(torch.bool)
+
+
+def token_gather(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 3 or not x.is_contiguous() or not x.is_cuda:
+        raise ValueError("token_gather: x must be a contiguous (B,N,D) device tensor")
+    _need(idx, torch.int32, "idx")
+    B, N, D = x.shape
+    if idx.dim() != 2 or idx.shape[0] != B or not idx.is_contiguous():
+        raise ValueError("token_gather: idx must be contiguous (B, N_keep) int32")
+    out = torch.empty(B, idx.shape[1], D, dtype=x.dtype, device=x.device)
+    check(_lib.load().va_token_gather(_p(x), _p(idx), _p(out), B, N, idx.shape[1], D * x.element_size(), _stream()),
+          "va_token_gather")
+    return out
+
+
+def token_scatter(src: torch.Tensor, idx: torch.Tensor, n_tokens: int) -> torch.Tensor:
+    if src.dim() != 3 or not src.is_contiguous() or not src.is_cuda:
+        raise ValueError("token_scatter: src must be a contiguous (B,N_keep,D) device tensor")
+    _need(idx, torch.int32, "idx")
+    B, Nk, D = src.shape
+    if tuple(idx.shape) != (B, Nk) or not idx.is_contiguous():
+        raise ValueError("token_scatter: idx must be contiguous (B, N_keep) int32")
+    out = torch.empty(B, n_tokens, D, dtype=src.dtype, device=src.device)
+    check(_lib.load().va_token_scatter(_p(src), _p(idx), _p(out), B, n_tokens, Nk, D * src.element_size(), _stream()),
+          "va_token_scatter")
+    return out
+
+
+def ema_update_(target: torch.Tensor, online: torch.Tensor, momentum: float, shadow_bf16: Optional[torch.Tensor] = None):
+    _need(target, F32, "target"); _need(online, F32, "online")
+    if target.numel() != online.numel() or not (target.is_contiguous() and online.is_contiguous()):
+        raise ValueError("ema_update_: target/online must be contiguous and equally sized")
+    if shadow_bf16 is not None:
+        _need(shadow_bf16, BF16, "shadow_bf16")
+    check(_lib.load().va_ema_update(_p(target), _p(online), _p(shadow_bf16), target.numel(), momentum, _stream()),
+          "va_ema_update")
+    return target
+
+
+def l1_loss(pred: torch.Tensor, target: torch.Tensor, want_grad: bool = True, grad_dtype=None):
+    """Returns (mean |pred - target| as a 0-d f32 tensor, d loss / d pred or None)."""
+    if pred.dtype != target.dtype or pred.dtype not in (BF16, F32) or pred.shape != target.shape:
+        raise ValueError("l1_loss: pred/target must share shape and dtype (bf16 or f32)")
+    if not (pred.is_cuda and pred.is_contiguous() and target.is_contiguous()):
+        raise ValueError("l1_loss: contiguous device tensors required")
+    n = pred.numel()
+    loss = torch.empty(1, dtype=F32, device=pred.device)
+    grad = torch.empty(pred.shape, dtype=grad_dtype or pred.dtype, device=pred.device) if want_grad else None
+    check(_lib.load().va_l1_loss(_p(pred), _p(target), int(pred.dtype == BF16), _p(loss), _p(grad),
+                                 int(grad is not None and grad.dtype == BF16), 1.0 / n, n, _stream()), "va_l1_loss")
+    return loss[0] / n, grad
