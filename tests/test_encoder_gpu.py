@@ -1,0 +1,131 @@
+"""GPU: the drop-in encoder (HIP path through the C ABI) against the reference's golden vectors and the
+CPU oracle, forward and backward.
+
+Stated tolerance (bf16 operands, f32 accumulation / residual stream / statistics):
+  relative L2 error  <= 2e-2 for activations and for every parameter gradient,
+  element-wise       |err| <= 3e-2 * max|ref| for activations.
+Mask indices and token moves are bit-exact (tests/test_kernels_gpu.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 2e-2
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def swm():
+    assert torch.cuda.is_available()
+    from vit_amd import surgical_world_model as m
+    return m
+
+
+def build(swm, depth, heads, frames, img):
+    enc = swm.VideoViTEncoder(img_size=img, num_frames=frames, embed_dim=1024, depth=depth, num_heads=heads).eval()
+    enc.load_state_dict(R.fill_state_dict_(enc.state_dict()))
+    return enc.cuda()
+
+
+@pytest.mark.parametrize("tag", ["d1h16", "d2h16", "d2h8"])
+def test_encoder_matches_reference_golden(swm, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"encoder_{tag}.npz"), allow_pickle=False)
+    depth, heads, B, frames, img = (int(v) for v in g["cfg"])
+    enc = build(swm, depth, heads, frames, img)
+    video = torch.from_numpy(g["video"]).cuda()
+    y = enc(video)
+    ref_y = torch.from_numpy(g["y"])
+    assert y.shape == ref_y.shape and y.dtype == torch.float32
+    assert rel(y, ref_y) < REL_TOL
+    assert (y.cpu() - ref_y).abs().max().item() < 3e-2 * ref_y.abs().max().item()
+    (y * torch.from_numpy(g["gy"]).cuda()).sum().backward()
+    worst = 0.0
+    for k, p in enc.named_parameters():
+        flat = p.grad.reshape(-1).double().cpu()
+        got, want = flat[torch.from_numpy(g[f"g:{k}:pos"])], torch.from_numpy(g[f"g:{k}:val"])
+        e = ((got - want).norm() / want.norm().clamp_min(1e-30)).item()
+        worst = max(worst, e)
+        assert e < 5e-2, (k, e)            # 64 sampled entries: looser than the full-tensor bound below
+        np.testing.assert_allclose(flat.abs().sum().item(), g[f"g:{k}:digest"][1], rtol=2e-2, err_msg=k)
+    print(f"[{tag}] y rel {rel(y, ref_y):.2e}, worst sampled-grad rel {worst:.2e}")
+
+
+@pytest.mark.parametrize("depth,heads,B,frames,img", [(2, 16, 2, 8, 64), (1, 8, 3, 4, 80), (1, 16, 2, 16, 224)])
+def test_encoder_matches_oracle_full_tensors(swm, depth, heads, B, frames, img):
+    """Full-tensor comparison of outputs and of every gradient with the fp32 CPU oracle; the last case is
+    the reference's CPU-runnable clip shape (16 x 224 x 224, 1568 tokens, batch 2) at depth 1."""
+    enc = build(swm, depth, heads, frames, img)
+    video = R.hashed_uniform(f"test.video.{depth}.{heads}.{img}", (B, 3, frames, img, img), 1.0)
+    P = R.make_encoder_params(depth, requires_grad=True)
+    ref = R.encoder_forward(P, video, depth, heads)
+    gy = R.hashed_uniform("test.gy", tuple(ref.shape), 1.0)
+    (ref * gy).sum().backward()
+    y = enc(video.cuda())
+    (y * gy.cuda()).sum().backward()
+    assert rel(y, ref) < REL_TOL
+    errs = {k: rel(p.grad, P[k].grad) for k, p in enc.named_parameters()}
+    bad = {k: e for k, e in errs.items() if not e < REL_TOL}
+    assert not bad, bad
+    print(f"y rel {rel(y, ref):.2e}; worst grad rel {max(errs.values()):.2e} ({max(errs, key=errs.get)})")
+
+
+def test_seeded_default_init_forward(swm, golden_dir):
+    """torch.manual_seed reproduces the reference's weights, so the reference's own output digest applies."""
+    g = np.load(os.path.join(golden_dir, "seed_canary.npz"), allow_pickle=False)
+    torch.manual_seed(0)
+    enc = swm.VideoViTEncoder(img_size=32, num_frames=4, embed_dim=1024, depth=1, num_heads=16).eval().cuda()
+    x = torch.randn(1, 3, 4, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    y = enc(x)
+    np.testing.assert_allclose(y.double().abs().sum().item(), float(g["y_abs_sum"]), rtol=5e-3)
+    np.testing.assert_allclose(y[0, 0, :8].detach().cpu().numpy(), g["y_head"], atol=2e-2)
+    (y ** 2).mean().backward()
+    np.testing.assert_allclose(enc.blocks[0].attn.qkv_proj.weight.grad.double().abs().sum().item(), float(g["dqkv_l1"]), rtol=3e-2)
+
+
+def test_full_size_properties(swm):
+    """ViT-L geometry (24 blocks, 16 heads, 16 x 256 x 256 clips = 2048 tokens): properties that need no
+    reference -- clips are independent (batch permutation commutes bit-exactly), the no-grad pass equals
+    the grad-saving pass bit-exactly, everything is finite, and repeated backward passes agree."""
+    torch.manual_seed(42)
+    enc = swm.VideoViTEncoder(img_size=256, num_frames=16, embed_dim=1024, depth=24, num_heads=16).eval().cuda()
+    video = torch.randn(3, 3, 16, 256, 256, generator=torch.Generator().manual_seed(1234)).cuda()
+    with torch.no_grad():
+        y0 = enc(video)
+        y_perm = enc(video[[2, 0, 1]])
+    assert y0.shape == (3, 2048, 1024) and torch.isfinite(y0).all()
+    assert torch.equal(y_perm, y0[[2, 0, 1]])
+    y1 = enc(video)
+    assert torch.equal(y1, y0)
+    (y1 ** 2).mean().backward()
+    g1 = {k: p.grad.clone() for k, p in enc.named_parameters()}
+    enc.zero_grad(set_to_none=True)
+    (enc(video) ** 2).mean().backward()
+    for k, p in enc.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        assert rel(p.grad, g1[k]) < 1e-4, k      # f32 atomics in the weight-gradient GEMM reorder sums
+
+
+def test_frozen_encoder_and_world_model_forward(swm):
+    m = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=8, encoder_depth=2, encoder_heads=16,
+                                                predictor_depth=3, predictor_heads=8).eval().cuda()
+    video = torch.randn(2, 3, 8, 32, 32).cuda()
+    actions, states = torch.randn(2, 8, 7).cuda(), torch.randn(2, 8, 7).cuda()
+    with torch.no_grad():
+        preds, now, fut = m(video, actions, states, predict_horizon=3, encoder_frozen=True)
+    assert len(preds) == 3 and now.shape == (2, 2) and fut.shape == (2, 2)
+    assert preds[0]["features"].shape == (2, 1024) and preds[2]["action_uncertainty"].shape == (2, 7)
+    assert all(torch.isfinite(v).all() for p in preds for v in p.values())
+    for p in m.encoder.parameters():
+        p.requires_grad_(False)
+    feats = m.encode_video(video)
+    assert not feats.requires_grad

@@ -1,0 +1,122 @@
+"""CPU: the drop-in module surface (names, shapes, assertions, init stream) without touching a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from vit_amd import _lib
+from vit_amd import surgical_world_model as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vit_amd.h")).read()
+    declared = set(re.findall(r"\b(va_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), "python binding table and header disagree"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vit_amd.h but not exported"
+    assert _lib.load().va_version() >= 100
+
+
+def test_encoder_state_dict_matches_reference_layout():
+    enc = M.VideoViTEncoder(img_size=32, num_frames=4, embed_dim=1024, depth=2, num_heads=16)
+    sd = enc.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if "inv_freq" not in k}
+    assert shapes == R.encoder_param_shapes(2)
+    assert list(shapes) == enc._param_order
+    assert tuple(sd["rope.inv_freq_t"].shape) == (128,) and tuple(sd["rope.inv_freq_h"].shape) == (192,)
+    assert torch.equal(sd["rope.inv_freq_w"], R.rope_inv_freq(384))
+
+
+def test_seed_reproduces_reference_initialisation(golden_dir):
+    g = np.load(os.path.join(golden_dir, "seed_canary.npz"), allow_pickle=False)
+    torch.manual_seed(0)
+    enc = M.VideoViTEncoder(img_size=32, num_frames=4, embed_dim=1024, depth=1, num_heads=16)
+    assert list(enc.state_dict().keys()) == [str(k) for k in g["keys"]]
+    np.testing.assert_allclose(enc.tubelet_embed.projection.weight.double().sum().item(), g["conv_w_sum"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(enc.blocks[0].attn.qkv_proj.weight.double().sum().item(), g["qkv_w_sum"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(enc.blocks[0].mlp[0].weight.double().sum().item(), g["fc1_w_sum"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(enc.blocks[0].mlp[3].bias.double().sum().item(), g["fc2_b_sum"], rtol=0, atol=1e-9)
+
+
+def test_constructor_assertions_match_reference():
+    with pytest.raises(AssertionError):       # 256+384+384 != 384
+        M.VideoViTEncoder(img_size=32, num_frames=4, embed_dim=384, depth=1, num_heads=6)
+    with pytest.raises(AssertionError):       # 1024 % 12 != 0  (the reference's own default crashes the same way)
+        M.VideoViTEncoder(img_size=32, num_frames=4, embed_dim=1024, depth=1)
+    with pytest.raises(ValueError):
+        M.TubeletEmbedding().inflate_weights_from_2d(torch.zeros(3, 3, 3))
+    te = M.TubeletEmbedding(img_size=32, num_frames=4)
+    te.inflate_weights_from_2d(torch.ones(1024, 3, 16, 16))
+    assert te.projection.weight[:, :, 0].abs().sum() == 0 and (te.projection.weight[:, :, 1] == 1).all()
+
+
+def test_world_model_surface():
+    m = M.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                              predictor_depth=3, predictor_heads=8)
+    assert m.encoder_dim == 1024 and m.predictor_dim == 1024 and m.tokens_per_frame == 4
+    assert m.encoder.tubelet_embed.num_temporal_patches == 2
+    keys = set(m.state_dict())
+    for k in ("video_proj.weight", "action_state_embed.inv_freq_t", "action_state_embed.action_proj.weight",
+              "predictor_blocks.0.spatial_attn.in_proj_weight", "predictor_blocks.0.spatial_attn.out_proj.bias",
+              "predictor_blocks.0.temporal_layer.q_conv1d.weight", "predictor_blocks.1.temporal_layer.o_norm.bias",
+              "predictor_blocks.2.mlp.2.bias", "predictor_norm.weight", "predictor_to_encoder.weight",
+              "sterility_classifier.current_classifier.4.weight", "sterility_classifier.future_classifier.1.bias",
+              "autoregressive_predictor.spatial_pooling.queries",
+              "autoregressive_predictor.spatial_pooling.attention.in_proj_weight",
+              "autoregressive_predictor.spatial_predictor.4.weight", "autoregressive_predictor.to_encoder_features.2.bias",
+              "autoregressive_predictor.action_predictor.5.weight", "autoregressive_predictor.state_uncertainty.2.bias"):
+        assert k in keys, k
+    # use_deltanet = i < depth*2//3  -> blocks 0,1 of 3
+    assert "predictor_blocks.2.temporal_layer.q_proj.weight" not in keys
+    # encoder on CPU must refuse loudly instead of silently computing somewhere else
+    with pytest.raises(_lib.VitAmdError):
+        m.encode_video(torch.zeros(1, 3, 4, 32, 32))
+
+
+def test_block_causal_mask_and_interleave():
+    mask = M.BlockCausalMask.create_mask(12, 4, "cpu")
+    ref = torch.ones(12, 12, dtype=torch.bool)
+    for t in range(3):
+        ref[t * 4:(t + 1) * 4, :(t + 1) * 4] = False
+    assert torch.equal(mask, ref)
+    mask = M.BlockCausalMask.create_mask(10, 4, "cpu")
+    ref = torch.ones(10, 10, dtype=torch.bool)
+    for t in range(2):
+        ref[t * 4:(t + 1) * 4, :(t + 1) * 4] = False
+    assert torch.equal(mask, ref)
+    m = M.SurgicalActionConditionedWorldModel.__new__(M.SurgicalActionConditionedWorldModel)
+    v = torch.arange(2 * 3 * 2 * 5).float().view(2, 3, 2, 5)
+    a, s = -torch.ones(2, 3, 5), -2 * torch.ones(2, 3, 5)
+    out = M.SurgicalActionConditionedWorldModel.interleave_tokens(m, v, a, s)
+    assert out.shape == (2, 12, 5)
+    assert torch.equal(out[:, 0:2], v[:, 0]) and (out[:, 2] == -1).all() and (out[:, 3] == -2).all()
+    assert torch.equal(out[:, 4:6], v[:, 1])
+
+
+def test_predictor_pieces_on_cpu():
+    """The predictor runs as torch ops, so its arithmetic can be exercised on CPU: the rank-1 delta rule
+    must equal the dense matrix form of the recurrence."""
+    torch.manual_seed(0)
+    layer = M.GatedDeltaLayer(64, num_heads=2, head_dim=32).eval()
+    B, L, H, D = 2, 7, 2, 32
+    q, k, v = (torch.nn.functional.normalize(torch.randn(B, L, H, D), dim=-1) for _ in range(3))
+    alpha, beta = torch.rand(B, L, H), torch.rand(B, L, H)
+    out, state = layer._sequential_gated_delta(q, k, v, alpha, beta, None)
+    S = torch.zeros(B, H, D, D)
+    eye = torch.eye(D)
+    for t in range(L):
+        kk = k[:, t, :, :, None] @ k[:, t, :, None, :]
+        S = S @ (alpha[:, t, :, None, None] * (eye - beta[:, t, :, None, None] * kk)) + \
+            beta[:, t, :, None, None] * (v[:, t, :, :, None] @ k[:, t, :, None, :])
+        np.testing.assert_allclose(out[:, t].numpy(), (S @ q[:, t, :, :, None]).squeeze(-1).numpy(), atol=1e-5)
+    np.testing.assert_allclose(state.numpy(), S.numpy(), atol=1e-5)
+    y, st = layer(torch.randn(B, L, 64))
+    assert y.shape == (B, L, 64) and st.shape == (B, 2, 32, 32)

@@ -9,6 +9,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
+# PyTorch-ROCm ships its own libamdhip64.so.7.  It must be the HIP runtime already resident when
+# libvit_amd.so is opened, so that the library's kernels launch into the runtime (and device context)
+# that owns torch's allocations and streams; opening the library first would pull in a second runtime.
+import torch  # noqa: F401  (import order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvit_amd.so")
 

@@ -1,0 +1,307 @@
+"""Host-side schedule of the encoder forward and backward over the C-ABI kernels.
+
+The engine replaces the eager op sequence of the reference's `VideoViTEncoder.forward`
+(surgical_world_model.py:772-817) and its autograd backward with explicit launches:
+
+  forward, per clip batch (M = B*N tokens, D = 1024):
+    tubelet gather -> patch GEMM(+bias, f32 out)                       [swm:92-109]
+    per block:  LN1 -> QKV GEMM -> 3D-RoPE in place -> flash attention  [swm:283-331]
+                -> out-proj GEMM (+residual, f32)                       [swm:334, 707]
+                -> LN2 -> fc1 GEMM (+bias, GELU) -> fc2 GEMM (+bias +residual, f32)  [swm:698-713]
+    final LN (f32 out)                                                  [swm:815]
+
+  backward mirrors it; every data-gradient GEMM runs against a transposed bf16 copy of the weight,
+  every weight-gradient GEMM accumulates in f32 into one flat gradient buffer per block, which is what
+  the data-parallel reducer all-reduces as soon as the block's backward has been enqueued.
+
+The residual stream, LayerNorm statistics, softmax statistics and all accumulators are f32; GEMM and
+attention operands are bf16.  Dropout (p = 0.1 in the reference's blocks, swm:752) is the identity here:
+this engine implements the eval-mode arithmetic the parity fixtures are defined on.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+LN_EPS = 1e-6
+
+BLOCK_PARAM_NAMES = ("norm1.weight", "norm1.bias", "attn.qkv_proj.weight", "attn.out_proj.weight",
+                     "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias")
+
+
+def encoder_param_names(depth: int) -> List[str]:
+    """Parameter order used across the autograd boundary (state-dict order of the reference encoder)."""
+    names = ["tubelet_embed.projection.weight", "tubelet_embed.projection.bias"]
+    for i in range(depth):
+        names += [f"blocks.{i}.{n}" for n in BLOCK_PARAM_NAMES]
+    names += ["norm.weight", "norm.bias"]
+    return names
+
+
+@dataclass
+class EncoderConfig:
+    depth: int
+    heads: int
+    dim: int = 1024
+    tubelet: Tuple[int, int, int] = (2, 16, 16)
+    in_channels: int = 3
+    temporal_scale: float = 0.6
+
+    def check(self):
+        if self.dim != 1024:
+            raise ops._lib.VitAmdError("the encoder kernels are specialised for width 1024 (the only width the "
+                                       "reference's 256/384/384 RoPE split admits)")
+        hd = self.dim // self.heads
+        if self.dim % self.heads or hd not in (64, 128):
+            raise ops._lib.VitAmdError(f"head dim {hd} (heads={self.heads}) has no attention kernel; use 16 or 8 heads")
+
+
+class WeightCache:
+    """bf16 (and transposed bf16) copies of the f32 master weights, refreshed when a parameter changes."""
+
+    def __init__(self):
+        self._fwd: Dict[str, Tuple[int, int, torch.Tensor]] = {}
+        self._bwd: Dict[str, Tuple[int, int, torch.Tensor]] = {}
+
+    @staticmethod
+    def _key(p: torch.Tensor):
+        return (p.data_ptr(), p._version)
+
+    def invalidate(self) -> None:
+        """Forget which parameter versions the copies were made from (the buffers are kept and reused)."""
+        self._fwd = {k: (0, -1, v[2]) for k, v in self._fwd.items()}
+        self._bwd = {k: (0, -1, v[2]) for k, v in self._bwd.items()}
+
+    def fwd(self, name: str, p: torch.Tensor) -> torch.Tensor:
+        ent = self._fwd.get(name)
+        if ent is None or (ent[0], ent[1]) != self._key(p):
+            w2d = p.detach().reshape(p.shape[0], -1)
+            buf = ent[2] if ent is not None and ent[2].shape == w2d.shape else None
+            ent = (*self._key(p), ops.cast_bf16(w2d, buf))
+            self._fwd[name] = ent
+        return ent[2]
+
+    def bwd(self, name: str, p: torch.Tensor) -> torch.Tensor:
+        ent = self._bwd.get(name)
+        if ent is None or (ent[0], ent[1]) != self._key(p):
+            w2d = p.detach().reshape(p.shape[0], -1)
+            buf = ent[2] if ent is not None and ent[2].shape == (w2d.shape[1], w2d.shape[0]) else None
+            ent = (*self._key(p), ops.cast_transpose_bf16(w2d, buf))
+            self._bwd[name] = ent
+        return ent[2]
+
+
+@dataclass
+class _BlockSaved:
+    x_in: torch.Tensor
+    mean1: torch.Tensor
+    rstd1: torch.Tensor
+    ln1: torch.Tensor
+    qkv: torch.Tensor
+    attn: torch.Tensor
+    lse2: torch.Tensor
+    x_mid: torch.Tensor
+    mean2: torch.Tensor
+    rstd2: torch.Tensor
+    ln2: torch.Tensor
+    pre: torch.Tensor
+    act: torch.Tensor
+
+
+@dataclass
+class EncoderContext:
+    cfg: EncoderConfig
+    B: int
+    N: int
+    grid: Tuple[int, int, int]
+    tables: torch.Tensor
+    patches: torch.Tensor
+    blocks: List[_BlockSaved] = field(default_factory=list)
+    x_last: Optional[torch.Tensor] = None
+    mean_f: Optional[torch.Tensor] = None
+    rstd_f: Optional[torch.Tensor] = None
+
+
+class EncoderEngine:
+    def __init__(self, cfg: EncoderConfig):
+        cfg.check()
+        self.cfg = cfg
+        self.weights = WeightCache()
+        self._tables: Dict[Tuple, torch.Tensor] = {}
+
+    # ---------------------------------------------------------------- helpers
+    def rope_tables(self, P: Dict[str, torch.Tensor], grid, device) -> torch.Tensor:
+        key = (grid, str(device))
+        t = self._tables.get(key)
+        if t is None:
+            t = ops.rope_tables_device(P["rope.inv_freq_t"], P["rope.inv_freq_h"], P["rope.inv_freq_w"], grid,
+                                       self.cfg.temporal_scale, device)
+            self._tables[key] = t
+        return t
+
+    def _geometry(self, video: torch.Tensor):
+        if video.dim() != 5:
+            raise ValueError(f"video must be (B,C,T,H,W), got {tuple(video.shape)}")
+        B, C, T, H, W = video.shape
+        tt, th, tw = self.cfg.tubelet
+        if C != self.cfg.in_channels:
+            raise ValueError(f"expected {self.cfg.in_channels} channels, got {C}")
+        grid = (T // tt, H // th, W // tw)
+        N = grid[0] * grid[1] * grid[2]
+        if N == 0:
+            raise ValueError("clip smaller than one tubelet")
+        return B, grid, N
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, P: Dict[str, torch.Tensor], video: torch.Tensor, save: bool):
+        """P: name -> f32 device tensor (parameters and the rope.inv_freq_* buffers).
+        Returns (features (B,N,D) f32, EncoderContext or None)."""
+        cfg = self.cfg
+        dev = video.device
+        if not video.is_cuda:
+            raise ops._lib.VitAmdError("VideoViTEncoder runs on a HIP device only (no CPU path)")
+        B, grid, N = self._geometry(video)
+        M, D, H = B * N, cfg.dim, cfg.heads
+        video = video.detach().to(F32).contiguous()
+        Wc = self.weights
+        tables = self.rope_tables(P, grid, dev)
+
+        def new(cols, dtype):
+            return torch.empty(M, cols, dtype=dtype, device=dev)
+
+        patches = ops.tubelet_gather(video, cfg.tubelet)
+        x = new(D, F32)
+        ops.gemm_nt(patches, Wc.fwd("pe", P["tubelet_embed.projection.weight"]), ops.EPI_F32, x,
+                    bias=P["tubelet_embed.projection.bias"])
+        ctx = EncoderContext(cfg, B, N, grid, tables, patches) if save else None
+
+        # without a backward the activations of one block are recycled for the next
+        scratch: Dict[str, torch.Tensor] = {}
+
+        def buf(name, cols, dtype):
+            if save:
+                return new(cols, dtype)
+            t = scratch.get(name)
+            if t is None:
+                t = scratch[name] = new(cols, dtype)
+            return t
+
+        def stat(name):
+            if save:
+                return torch.empty(M, dtype=F32, device=dev)
+            t = scratch.get(name)
+            if t is None:
+                t = scratch[name] = torch.empty(M, dtype=F32, device=dev)
+            return t
+
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            mean1, rstd1 = stat("mean1"), stat("rstd1")
+            ln1 = buf("ln1", D, BF16)
+            ops.layernorm_fwd(x, P[p + "norm1.weight"], P[p + "norm1.bias"], ln1, mean1, rstd1, LN_EPS)
+            qkv = buf("qkv", 3 * D, BF16)
+            ops.gemm_nt(ln1, Wc.fwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, qkv)
+            ops.rope3d_qk_(qkv, tables, grid)
+            attn = buf("attn", D, BF16)
+            lse2 = torch.empty(B * H, N, dtype=F32, device=dev) if save else scratch.setdefault(
+                "lse2", torch.empty(B * H, N, dtype=F32, device=dev))
+            ops.attn_fwd(qkv, B, N, H, attn, lse2)
+            x_mid = buf("x_mid", D, F32) if save else buf("x_mid" + str(i & 1), D, F32)
+            ops.gemm_nt(attn, Wc.fwd(p + "out", P[p + "attn.out_proj.weight"]), ops.EPI_F32, x_mid, resid=x)
+            mean2, rstd2 = stat("mean2"), stat("rstd2")
+            ln2 = buf("ln2", D, BF16)
+            ops.layernorm_fwd(x_mid, P[p + "norm2.weight"], P[p + "norm2.bias"], ln2, mean2, rstd2, LN_EPS)
+            pre, act = buf("pre", 4 * D, BF16), buf("act", 4 * D, BF16)
+            ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BIAS_GELU, pre, out2=act,
+                        bias=P[p + "mlp.0.bias"])
+            x_next = buf("x_out", D, F32) if save else buf("x_out" + str(i & 1), D, F32)
+            ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next, bias=P[p + "mlp.3.bias"],
+                        resid=x_mid)
+            if save:
+                ctx.blocks.append(_BlockSaved(x, mean1, rstd1, ln1, qkv, attn, lse2, x_mid, mean2, rstd2, ln2, pre, act))
+            x = x_next
+
+        y = new(D, F32)
+        mean_f, rstd_f = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
+        ops.layernorm_fwd(x, P["norm.weight"], P["norm.bias"], y, mean_f, rstd_f, LN_EPS)
+        if save:
+            ctx.x_last, ctx.mean_f, ctx.rstd_f = x, mean_f, rstd_f
+        return y.view(B, N, D), ctx
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, P: Dict[str, torch.Tensor], ctx: EncoderContext, grad_out: torch.Tensor,
+                 on_block_done: Optional[Callable[[torch.Tensor], None]] = None) -> Dict[str, torch.Tensor]:
+        """grad_out: (B,N,D).  Returns name -> f32 gradient (views into one flat buffer per block).
+        `on_block_done(flat)` is called right after a block's (and finally the stem's) gradient launches
+        have been enqueued; the data-parallel reducer hooks in there."""
+        cfg = self.cfg
+        B, N, grid, tables = ctx.B, ctx.N, ctx.grid, ctx.tables
+        M, D, H = B * N, cfg.dim, cfg.heads
+        dev = grad_out.device
+        Wc = self.weights
+        gy = grad_out.detach().to(F32).contiguous().view(M, D)
+        grads: Dict[str, torch.Tensor] = {}
+
+        def carve(names_shapes):
+            total = sum(int(torch.Size(s).numel()) for _, s in names_shapes)
+            total_padded = (total + 3) // 4 * 4
+            flat = torch.zeros(total_padded, dtype=F32, device=dev)
+            off = 0
+            for nme, shp in names_shapes:
+                n = int(torch.Size(shp).numel())
+                grads[nme] = flat[off:off + n].view(shp)
+                off += n
+            return flat
+
+        g_a = torch.empty(M, D, dtype=F32, device=dev)
+        g_b = torch.empty(M, D, dtype=F32, device=dev)
+        g_bf = torch.empty(M, D, dtype=BF16, device=dev)
+        d_small = torch.empty(M, D, dtype=BF16, device=dev)       # dLN inputs / dO
+        d_wide = torch.empty(M, 4 * D, dtype=BF16, device=dev)    # d(pre-activation)
+        dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+
+        tail = carve([("norm.weight", (D,)), ("norm.bias", (D,))])
+        ops.layernorm_bwd(gy, ctx.x_last, P["norm.weight"], ctx.mean_f, ctx.rstd_f, None, g_a, g_bf,
+                          grads["norm.weight"], grads["norm.bias"])
+        if on_block_done is not None:
+            on_block_done(tail)
+        ctx.x_last = None
+
+        for i in reversed(range(cfg.depth)):
+            p = f"blocks.{i}."
+            s = ctx.blocks[i]
+            flat = carve([(p + n, tuple(P[p + n].shape)) for n in BLOCK_PARAM_NAMES])
+            # ---- MLP
+            ops.gemm_nt(g_bf, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_GELU_BWD, d_wide, aux=s.pre)
+            ops.gemm_tn_accum(g_bf, s.act, grads[p + "mlp.3.weight"])
+            ops.colsum_accum(g_bf, grads[p + "mlp.3.bias"])
+            ops.gemm_nt(d_wide, Wc.bwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BF16, d_small)
+            ops.gemm_tn_accum(d_wide, s.ln2, grads[p + "mlp.0.weight"])
+            ops.colsum_accum(d_wide, grads[p + "mlp.0.bias"])
+            ops.layernorm_bwd(d_small, s.x_mid, P[p + "norm2.weight"], s.mean2, s.rstd2, g_a, g_b, g_bf,
+                              grads[p + "norm2.weight"], grads[p + "norm2.bias"])
+            # ---- attention
+            ops.gemm_nt(g_bf, Wc.bwd(p + "out", P[p + "attn.out_proj.weight"]), ops.EPI_BF16, d_small)
+            ops.gemm_tn_accum(g_bf, s.attn, grads[p + "attn.out_proj.weight"])
+            ops.attn_bwd(s.qkv, s.attn, d_small, s.lse2, dqkv, B, N, H)
+            ops.rope3d_qk_(dqkv, tables, grid, inverse=True)
+            ops.gemm_nt(dqkv, Wc.bwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, d_small)
+            ops.gemm_tn_accum(dqkv, s.ln1, grads[p + "attn.qkv_proj.weight"])
+            ops.layernorm_bwd(d_small, s.x_in, P[p + "norm1.weight"], s.mean1, s.rstd1, g_b, g_a, g_bf,
+                              grads[p + "norm1.weight"], grads[p + "norm1.bias"])
+            if on_block_done is not None:
+                on_block_done(flat)
+            ctx.blocks[i] = None   # release this block's activations
+
+        pw = P["tubelet_embed.projection.weight"]
+        stem = carve([("tubelet_embed.projection.weight", tuple(pw.shape)), ("tubelet_embed.projection.bias", (D,))])
+        ops.gemm_tn_accum(g_bf, ctx.patches, grads["tubelet_embed.projection.weight"].view(D, -1))
+        ops.colsum_accum(g_bf, grads["tubelet_embed.projection.bias"])
+        if on_block_done is not None:
+            on_block_done(stem)
+        return grads
