@@ -50,9 +50,10 @@ int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, int64_t K, in
 /* dw[N,K] (f32) += dy[M,N]^T * x[M,K]: the weight-gradient half of nn.Linear's backward (autograd of
  * swm:296, 334, 698-701, 102).  bf16 operands, split over M in `split_k` slices (0 = choose) that are
  * combined with f32 atomic adds, so `dw` must hold the value to accumulate onto (zeros for a fresh
- * gradient).  N % 128 == 0, K % 128 == 0; any M. */
+ * gradient).  If dbias != NULL, dbias[N] (f32) += column sums of dy (the bias gradient) in the same pass.
+ * N % 128 == 0, K % 128 == 0; any M. */
 int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_t N, int64_t K, int64_t lddy, int64_t ldx,
-                     float* dw, int64_t lddw, int split_k, va_stream_t stream);
+                     float* dw, int64_t lddw, float* dbias, int split_k, va_stream_t stream);
 
 /* out[N] (f32) += column sums of y[M,N] (bf16): bias gradients (autograd of swm:698, 701, 78). */
 int va_colsum_bf16_accum(const void* y, int64_t M, int64_t N, int64_t ldy, float* out, va_stream_t stream);

@@ -108,11 +108,13 @@ def test_gemm_tn(ops, dev, M, N, K, split):
     dy = rnd((M, N), dev, 7, dtype=BF16)
     x = rnd((M, K), dev, 8, dtype=BF16)
     dw = torch.ones(N, K, dtype=F32, device=dev)
-    ops.gemm_tn_accum(dy, x, dw, split_k=split)
+    db = torch.full((N,), 2.0, dtype=F32, device=dev)
+    ops.gemm_tn_accum(dy, x, dw, dbias=db, split_k=split)
     ref = dy.float().t() @ x.float() + 1.0
     assert torch.isfinite(dw).all()
     assert rel_err(dw, ref) < 1e-4
     assert (dw - ref).abs().max().item() < 1e-3 * math.sqrt(M)
+    assert (db - (dy.float().sum(0) + 2.0)).abs().max().item() < 2e-4 * math.sqrt(M) + 1e-3
 
 
 def test_gemm_tn_layout(ops, dev):

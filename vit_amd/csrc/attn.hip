@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // dK/dV pass: key-stationary, streams Q and dO (plus the per-query lse2 and delta).
 // ------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
                                                            const float* __restrict__ LSE2,
                                                            const float* __restrict__ DELTA, bf16_t* __restrict__ DK,

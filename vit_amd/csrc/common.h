@@ -63,12 +63,31 @@ VA_DEVINL void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // Row of accumulator register i in lane-half h for a 32x32 MFMA result.
 VA_DEVINL int acc32_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// Exact-erf GELU and its derivative.
-VA_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact (erf-form) GELU and its derivative.  erf comes from the Abramowitz-Stegun 7.1.26 rational
+// form (|error| <= 1.5e-7, below f32 rounding of the result for the bf16 outputs produced here): one
+// v_rcp_f32, one v_exp_f32 and five FMAs instead of the branchy library erff, because the GEMM epilogues
+// that call this run on a CU whose matrix pipe idles meanwhile.  exp(-x^2/2) is shared between the
+// normal CDF and the normal PDF of the derivative.
+VA_DEVINL void gelu_parts(float x, float& cdf, float& gauss) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    gauss = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);            // exp(-x^2/2)
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float half_erfc = 0.5f * poly * t * gauss;                          // 0.5 * erfc(|x|/sqrt2)
+    cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+}
+VA_DEVINL float gelu_erf(float x) {
+    float cdf, g;
+    gelu_parts(x, cdf, g);
+    return x * cdf;
+}
 VA_DEVINL float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, g;
+    gelu_parts(x, cdf, g);
+    return fmaf(x * 0.39894228040143268f, g, cdf);
 }
 
 // Map a launch-order block id onto a work id so that the blocks that share an XCD (ids equal mod 8)

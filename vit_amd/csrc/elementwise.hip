@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-constexpr int LN_BWD_BLOCKS = 1024;   // upper bound on the number of partial rows
+constexpr int LN_BWD_BLOCKS = 512;    // upper bound on the number of partial rows
 
 // Each wave walks rows wave_id, wave_id + n_waves, ...; dgamma/dbeta partial sums stay in registers,
 // are combined across the 4 waves of the block through LDS and written as one partial row per block.
@@ -154,23 +154,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
-// dgamma[c] = sum_b partial[b][0][c], dbeta[c] = sum_b partial[b][1][c]; block = 256 threads = 64 columns x 4.
+// dgamma[c] = sum_b partial[b][0][c], dbeta[c] = sum_b partial[b][1][c].  Block = 16 columns x 16 row
+// lanes; grid = 2 * D / 16 blocks (first half dgamma, second half dbeta).
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[2][4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-    float a = 0.f, b = 0.f;
-    for (int r = part; r < nblk; r += 4) {
-        a += partial[((int64_t)r * 2 + 0) * LN_D + c];
-        b += partial[((int64_t)r * 2 + 1) * LN_D + c];
-    }
-    red[0][part][threadIdx.x & 63] = a;
-    red[1][part][threadIdx.x & 63] = b;
+    __shared__ float red[16][17];
+    const int which = blockIdx.x / (LN_D / 16);
+    const int c = (blockIdx.x % (LN_D / 16)) * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    float a = 0.f;
+    for (int r = part; r < nblk; r += 16) a += partial[((int64_t)r * 2 + which) * LN_D + c];
+    red[part][threadIdx.x & 15] = a;
     __syncthreads();
     if (part == 0) {
-        const int i = threadIdx.x;
-        dgamma[c] = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
-        dbeta[c] = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+        (which == 0 ? dgamma : dbeta)[c] = t;
     }
 }
 
@@ -440,7 +439,7 @@ extern "C" int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, con
         hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, dy, x, gamma, mean, rstd, resid_grad,
                            dx_out, (bf16_t*)dx_bf16, partial, M);
     VA_CHECK_LAUNCH("va_layernorm_bwd");
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(LN_D / 64), dim3(256), 0, stream, partial, nblk, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * LN_D / 16), dim3(256), 0, stream, partial, nblk, dgamma, dbeta);
     VA_CHECK_LAUNCH("va_layernorm_bwd(reduce)");
     return VA_OK;
 }

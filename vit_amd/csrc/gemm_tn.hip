@@ -13,6 +13,8 @@
 //     the MFMA A operand, so one accumulator register across a wave is two 128-byte row segments of dW,
 //     the shape at which the memory-side atomic units run at full rate.
 //   * a ragged last M-tile is zero-filled in LDS after it lands (sources are clamped to row M-1).
+//   * the bias gradient (column sums of dY) is optionally fused: one extra MFMA against an all-ones
+//     operand reuses the dY^T fragments that are in registers anyway, instead of a second pass over dY.
 #include "common.h"
 
 namespace {
@@ -24,7 +26,7 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
                                                       int M, int N, int K, int lddy, int ldx, float* __restrict__ DW,
-                                                      int lddw, int m_per_slice) {
+                                                      int lddw, int m_per_slice, float* __restrict__ DBIAS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,6 +77,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
+    // Optional fused bias gradient (column sums of dY): the workgroups of k-tile 0 multiply their dY^T
+    // fragments with an all-ones B operand as well; the two k-waves of a row share the k-steps.
+    const bool do_bias = (DBIAS != nullptr) && (id % tiles_k == 0);
+    f32x16_t bacc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bacc[a][i] = 0.f;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+
     // transposed-read lane roles: 16-lane group gi = lane>>4: column half cg = gi&1, k half h = gi>>1;
     // inside the group lane 4q+p addresses row q, columns 4p..4p+3.
     const int gi = lane >> 4, cg = gi & 1, h = gi >> 1, q = (lane & 15) >> 2, p = lane & 3;
@@ -108,6 +120,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(af[a], bfr[b], acc[a][b]);
+            if (do_bias && (ks & 1) == wk) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) bacc[a] = mfma32(af[a], ones, bacc[a]);
+            }
         }
     };
 
@@ -150,12 +166,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 16; ++i) unsafeAtomicAdd(base + (size_t)acc32_row(i, hh) * lddw, acc[a][b][i]);
         }
+    if (do_bias && col == 0) {   // every column of bacc holds the same sums: lane column 0 publishes them
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) unsafeAtomicAdd(DBIAS + n0 + wn * 64 + a * 32 + acc32_row(i, hh), bacc[a][i]);
+    }
 }
 
 }  // namespace
 
 extern "C" int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_t N, int64_t K, int64_t lddy,
-                                int64_t ldx, float* dw, int64_t lddw, int split_k, hipStream_t stream) {
+                                int64_t ldx, float* dw, int64_t lddw, float* dbias, int split_k,
+                                hipStream_t stream) {
     VA_CHECK_ARG(dy && x && dw, "va_gemm_tn_accum: null operand");
     VA_CHECK_ARG(M > 0 && N > 0 && K > 0, "va_gemm_tn_accum: empty problem");
     VA_CHECK_ARG(N % 128 == 0 && K % 128 == 0, "va_gemm_tn_accum: N=%lld and K=%lld must be multiples of 128",
@@ -189,7 +212,7 @@ extern "C" int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_
         attr_set[dev] = true;
     }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, slices), dim3(256), 2 * STAGE_BYTES, stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, (int)M, (int)N, (int)K, (int)lddy, (int)ldx, dw, (int)lddw, m_per_slice);
+                       (const bf16_t*)x, (int)M, (int)N, (int)K, (int)lddy, (int)ldx, dw, (int)lddw, m_per_slice, dbias);
     VA_CHECK_LAUNCH("va_gemm_tn_accum");
     return VA_OK;
 }

@@ -278,11 +278,9 @@ class EncoderEngine:
             flat = carve([(p + n, tuple(P[p + n].shape)) for n in BLOCK_PARAM_NAMES])
             # ---- MLP
             ops.gemm_nt(g_bf, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_GELU_BWD, d_wide, aux=s.pre)
-            ops.gemm_tn_accum(g_bf, s.act, grads[p + "mlp.3.weight"])
-            ops.colsum_accum(g_bf, grads[p + "mlp.3.bias"])
+            ops.gemm_tn_accum(g_bf, s.act, grads[p + "mlp.3.weight"], dbias=grads[p + "mlp.3.bias"])
             ops.gemm_nt(d_wide, Wc.bwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BF16, d_small)
-            ops.gemm_tn_accum(d_wide, s.ln2, grads[p + "mlp.0.weight"])
-            ops.colsum_accum(d_wide, grads[p + "mlp.0.bias"])
+            ops.gemm_tn_accum(d_wide, s.ln2, grads[p + "mlp.0.weight"], dbias=grads[p + "mlp.0.bias"])
             ops.layernorm_bwd(d_small, s.x_mid, P[p + "norm2.weight"], s.mean2, s.rstd2, g_a, g_b, g_bf,
                               grads[p + "norm2.weight"], grads[p + "norm2.bias"])
             # ---- attention
@@ -300,8 +298,8 @@ class EncoderEngine:
 
         pw = P["tubelet_embed.projection.weight"]
         stem = carve([("tubelet_embed.projection.weight", tuple(pw.shape)), ("tubelet_embed.projection.bias", (D,))])
-        ops.gemm_tn_accum(g_bf, ctx.patches, grads["tubelet_embed.projection.weight"].view(D, -1))
-        ops.colsum_accum(g_bf, grads["tubelet_embed.projection.bias"])
+        ops.gemm_tn_accum(g_bf, ctx.patches, grads["tubelet_embed.projection.weight"].view(D, -1),
+                          dbias=grads["tubelet_embed.projection.bias"])
         if on_block_done is not None:
             on_block_done(stem)
         return grads

@@ -65,16 +65,21 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, epilogue: int, out: torch.Tensor, 
     return out
 
 
-def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, split_k: int = 0) -> torch.Tensor:
-    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]."""
+def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor] = None,
+                  split_k: int = 0) -> torch.Tensor:
+    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]; optionally dbias[N] (f32) += dy.sum(0) in the same pass."""
     _need(dy, BF16, "dy"); _need(x, BF16, "x"); _need(dw, F32, "dw")
     M, N = dy.shape
     M2, K = x.shape
     if M2 != M or tuple(dw.shape) != (N, K):
         raise ValueError(f"gemm_tn_accum: shapes dy{tuple(dy.shape)} x{tuple(x.shape)} dw{tuple(dw.shape)}")
+    if dbias is not None:
+        _need(dbias, F32, "dbias")
+        if dbias.numel() != N or not dbias.is_contiguous():
+            raise ValueError("gemm_tn_accum: dbias must be a contiguous [N] vector")
     lib = _lib.load()
-    check(lib.va_gemm_tn_accum(_p(dy), _p(x), M, N, K, _ld(dy), _ld(x), _p(dw), _ld(dw), split_k, _stream()),
-          "va_gemm_tn_accum")
+    check(lib.va_gemm_tn_accum(_p(dy), _p(x), M, N, K, _ld(dy), _ld(x), _p(dw), _ld(dw), _p(dbias), split_k,
+                               _stream()), "va_gemm_tn_accum")
     return dw
 
 
