@@ -160,7 +160,7 @@ def main():
             achieved = ps["flops"] / ps["seconds"] / 1e12
             roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_FLOPS / 1e12,
                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_FLOPS, 4), "traffic": None,
-                        "kernel": "gemm_nt_kernel<256,256,2,4,bf16-out>", "launches": ps["launches"],
+                        "kernel": "gemm_nt_ring_kernel<bf16-out> (256x256 tile)", "launches": ps["launches"],
                         "avg_launch_ms": round(ps["seconds"] * 1e3 / ps["launches"], 4)}
         out = {
             "metric": "video clips/sec (ViT-L fwd+bwd, 16x256^2)", "value": round(value, 3), "unit": "clips/s",

@@ -4,17 +4,26 @@
 // tubelet gather), QKV, attention out-projection, MLP fc1 / fc2, and all data-gradient GEMMs (which
 // run against a transposed bf16 copy of the weight so that they have the same K-contiguous shape).
 //
-// Structure (gfx950):
-//   * workgroup tile BM x BN x 64, double-buffered in LDS, staged with 16-byte direct-to-LDS loads
-//     (global_load_lds_dwordx4).  The LDS image is lane-linear; bank conflicts of the ds_read_b128
-//     fragment reads are removed by permuting the per-lane SOURCE address (16-byte chunk index XOR
-//     ((row>>1)&7)) and applying the same XOR when reading.
+// Common structure (gfx950):
+//   * operand tiles are staged with 16-byte direct-to-LDS loads (global_load_lds_dwordx4).  The LDS image
+//     is lane-linear; bank conflicts of the ds_read_b128 fragment reads are removed by permuting the
+//     per-lane SOURCE address (XOR on the 16-byte chunk index) and applying the same XOR when reading.
 //   * each wave owns a (BM/WM) x (BN/WN) sub-tile as 16x16x32 bf16 MFMAs.  The weight tile is the MFMA
 //     A operand and the activation tile the B operand, so an accumulator lane holds 4 consecutive
 //     output columns of one output row: stores are 8-byte (bf16) / 16-byte (f32) vectors.
-//   * one barrier per K-tile: the next tile's loads are issued before the current tile's MFMAs.
 //   * launch-order block ids are remapped so that the blocks sharing an XCD walk neighbouring tiles.
+//
+// Two main loops:
+//   ring  (256x256 tile, 8 waves): K advances in 32-wide stages through a 4-slot LDS ring (4 x 32 KiB);
+//         loads run three stages ahead and are retired with COUNTED s_waitcnt vmcnt(N) in front of a raw
+//         s_barrier, so a stage stays in flight across every barrier.  MFMA fragments are read from LDS
+//         one stage ahead of their use, interleaved with the MFMAs of the current stage, so the LDS pipe
+//         and the matrix pipe overlap.  One barrier per 32 MFMAs per wave.
+//   pair  (128x128 tile, 4 waves; also selectable at 256x256): K advances in 64-wide tiles through two
+//         buffers, next tile issued before the current tile's MFMAs, vmcnt(0) + barrier per tile.  Used
+//         for small M and short K.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -27,115 +36,18 @@ struct EpiArgs {
     int ldc;
 };
 
-constexpr int BK = 64;
-
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const bf16_t* __restrict__ X,
-                                                               const bf16_t* __restrict__ W, int M, int N, int K,
-                                                               int ldx, int ldw, EpiArgs ep) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int TM = BM / WM / 16;
-    constexpr int TN = BN / WN / 16;
-    constexpr int X_BYTES = BM * BK * 2;
-    constexpr int W_BYTES = BN * BK * 2;
-    constexpr int STAGE_BYTES = X_BYTES + W_BYTES;
-    constexpr int XI = BM * 8 / NT;   // 16-byte chunks per thread per X tile
-    constexpr int WI = BN * 8 / NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    const int tiles_n = N / BN;
-    const int tiles_m = (M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (id / tiles_n) * BM;
-    const int n0 = (id % tiles_n) * BN;
-
-    // per-thread source pointers (row and swizzled chunk are fixed; only k advances)
-    const bf16_t* xsrc[XI];
-    const bf16_t* wsrc[WI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int q = i * NT + tid, row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-        int grow = m0 + row;
-        grow = grow < M ? grow : M - 1;
-        xsrc[i] = X + (size_t)grow * ldx + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-        const int q = i * NT + tid, row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-        wsrc[i] = W + (size_t)(n0 + row) * ldw + c * 8;
-    }
-
-    auto stage = [&](int buf, int k0) {
-        char* xb = smem + buf * STAGE_BYTES;
-        char* wb = xb + X_BYTES;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) glds16(xsrc[i] + k0, xb + (i * NT + wave * 64) * 16);
-#pragma unroll
-        for (int i = 0; i < WI; ++i) glds16(wsrc[i] + k0, wb + (i * NT + wave * 64) * 16);
-    };
-
-    f32x4_t acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    // fragment read offsets inside a tile (bytes), for k-step 0; k-step 1 flips chunk bit 2
-    const int frow = lane & 15, fchunk = lane >> 4;
-    int woff[TN], xoff[TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a) {
-        const int row = wn * (BN / WN) + a * 16 + frow;
-        woff[a] = row * 128 + ((fchunk ^ ((row >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int row = wm * (BM / WM) + b * 16 + frow;
-        xoff[b] = row * 128 + ((fchunk ^ ((row >> 1) & 7)) << 4);
-    }
-
-    auto compute = [&](int buf) {
-        const char* xb = smem + buf * STAGE_BYTES;
-        const char* wb = xb + X_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[TN], bfr[TM];
-#pragma unroll
-            for (int a = 0; a < TN; ++a) af[a] = *(const bf16x8_t*)(wb + (woff[a] ^ (kk << 6)));
-#pragma unroll
-            for (int b = 0; b < TM; ++b) bfr[b] = *(const bf16x8_t*)(xb + (xoff[b] ^ (kk << 6)));
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int b = 0; b < TM; ++b) acc[a][b] = mfma16(af[a], bfr[b], acc[a][b]);
-        }
-    };
-
-    const int nk = K / BK;
-    stage(0, 0);
-    wait_vm0();
-    __syncthreads();
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        stage((kt + 1) & 1, (kt + 1) * BK);
-        compute(kt & 1);
-        wait_vm0();
-        __syncthreads();
-    }
-    compute((nk - 1) & 1);
-
-    // ---- epilogue: lane holds rows n = nb..nb+3 of D for column m -> 4 consecutive output columns
+// Epilogue for a wave's accumulators acc[a][b] (a: 16-column block of n, b: 16-row block of m).
+// Lane holds D rows n = nb..nb+3 (4 consecutive output columns) for output row m.
+template <int EPI, int TM, int TN>
+VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
     const int ldc = ep.ldc;
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm * (BM / WM) + b * 16 + (lane & 15);
+        const int m = m_wave + b * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
-            const int nb = n0 + wn * (BN / WN) + a * 16 + (lane >> 4) * 4;
+            const int nb = n_wave + a * 16 + (lane >> 4) * 4;
             const size_t o = (size_t)m * ldc + nb;
             float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
             if (EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
@@ -170,21 +82,355 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const bf16_t* __re
     }
 }
 
+// Epilogue for the column-permuted layout of the ring kernel: the weight rows are staged so that MFMA
+// row r of 16-row block a is output column (r>>2)*16 + a*4 + (r&3) of the wave's 64 columns.  A lane then
+// owns 16 CONSECUTIVE output columns of one output row (32 B of bf16 / 64 B of f32), and the four lane
+// groups of a wave write one full 128-byte line of bf16 per output row.
+template <int EPI, int TM>
+VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
+    const int ldc = ep.ldc;
+    const int nb = n_wave + (lane >> 4) * 16;
+    float bias[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bias[j] = 0.f;
+    if (EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(f32x4_t*)(bias + 4 * g) = *(const f32x4_t*)(ep.bias + nb + 4 * g);
+    }
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m_wave + b * 16 + (lane & 15);
+        if (m >= M) continue;
+        const size_t o = (size_t)m * ldc + nb;
+        float v[16];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * a + j] = acc[a][b][j] + bias[4 * a + j];
+        if (EPI == VA_EPI_BF16) {
+            u32x4_t lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            u32x4_t hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
+            *(u32x4_t*)((bf16_t*)ep.out + o) = lo;
+            *(u32x4_t*)((bf16_t*)ep.out + o + 8) = hi;
+        } else if (EPI == VA_EPI_BIAS_GELU) {
+            u32x4_t lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            u32x4_t hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
+            *(u32x4_t*)((bf16_t*)ep.out + o) = lo;
+            *(u32x4_t*)((bf16_t*)ep.out + o + 8) = hi;
+            float g[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) g[j] = gelu_erf(v[j]);
+            u32x4_t glo = {pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]), pack_bf16x2(g[4], g[5]), pack_bf16x2(g[6], g[7])};
+            u32x4_t ghi = {pack_bf16x2(g[8], g[9]), pack_bf16x2(g[10], g[11]), pack_bf16x2(g[12], g[13]), pack_bf16x2(g[14], g[15])};
+            *(u32x4_t*)((bf16_t*)ep.out2 + o) = glo;
+            *(u32x4_t*)((bf16_t*)ep.out2 + o + 8) = ghi;
+        } else if (EPI == VA_EPI_F32) {
+            if (ep.resid != nullptr) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t rv = *(const f32x4_t*)(ep.resid + o + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[4 * g + j] += rv[j];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4_t*)((float*)ep.out + o + 4 * g) = (f32x4_t){v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        } else {  // VA_EPI_GELU_BWD
+            const u32x4_t p_lo = *(const u32x4_t*)(ep.aux + o);
+            const u32x4_t p_hi = *(const u32x4_t*)(ep.aux + o + 8);
+            float r[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[2 * j] = v[2 * j] * gelu_erf_grad(__uint_as_float(p_lo[j] << 16));
+                r[2 * j + 1] = v[2 * j + 1] * gelu_erf_grad(__uint_as_float(p_lo[j] & 0xffff0000u));
+                r[8 + 2 * j] = v[8 + 2 * j] * gelu_erf_grad(__uint_as_float(p_hi[j] << 16));
+                r[9 + 2 * j] = v[9 + 2 * j] * gelu_erf_grad(__uint_as_float(p_hi[j] & 0xffff0000u));
+            }
+            u32x4_t lo = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
+            u32x4_t hi = {pack_bf16x2(r[8], r[9]), pack_bf16x2(r[10], r[11]), pack_bf16x2(r[12], r[13]), pack_bf16x2(r[14], r[15])};
+            *(u32x4_t*)((bf16_t*)ep.out + o) = lo;
+            *(u32x4_t*)((bf16_t*)ep.out + o + 8) = hi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// "pair" loop: BK = 64, two LDS buffers.  Rows are 128 B (8 chunks); chunk XOR ((row>>1)&7).
+// ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int EPI>
-int launch_cfg(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
-               hipStream_t stream) {
-    constexpr int LDS = 2 * (BM + BN) * BK * 2;
-    auto kern = gemm_nt_kernel<BM, BN, WM, WN, EPI>;
-    static bool attr_set[64] = {};
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pair_kernel(const bf16_t* __restrict__ X,
+                                                                    const bf16_t* __restrict__ W, int M, int N, int K,
+                                                                    int ldx, int ldw, EpiArgs ep) {
+    constexpr int BK = 64;
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 16;
+    constexpr int TN = BN / WN / 16;
+    constexpr int X_BYTES = BM * BK * 2;
+    constexpr int W_BYTES = BN * BK * 2;
+    constexpr int STAGE_BYTES = X_BYTES + W_BYTES;
+    constexpr int XI = BM * 8 / NT;   // 16-byte chunks per thread per X tile
+    constexpr int WI = BN * 8 / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tiles_n = N / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (id / tiles_n) * BM;
+    const int n0 = (id % tiles_n) * BN;
+
+    const bf16_t* xsrc[XI];
+    const bf16_t* wsrc[WI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int q = i * NT + tid, row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+        int grow = m0 + row;
+        grow = grow < M ? grow : M - 1;
+        xsrc[i] = X + (size_t)grow * ldx + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int q = i * NT + tid, row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+        wsrc[i] = W + (size_t)(n0 + row) * ldw + c * 8;
+    }
+
+    auto stage = [&](int buf, int k0) {
+        char* xb = smem + buf * STAGE_BYTES;
+        char* wb = xb + X_BYTES;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) glds16(xsrc[i] + k0, xb + (i * NT + wave * 64) * 16);
+#pragma unroll
+        for (int i = 0; i < WI; ++i) glds16(wsrc[i] + k0, wb + (i * NT + wave * 64) * 16);
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int woff[TN], xoff[TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        const int row = wn * (BN / WN) + a * 16 + frow;
+        woff[a] = row * 128 + ((fchunk ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int row = wm * (BM / WM) + b * 16 + frow;
+        xoff[b] = row * 128 + ((fchunk ^ ((row >> 1) & 7)) << 4);
+    }
+
+    auto compute = [&](int buf) {
+        const char* xb = smem + buf * STAGE_BYTES;
+        const char* wb = xb + X_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {   // k-step 1 flips chunk bit 2
+            bf16x8_t af[TN], bfr[TM];
+#pragma unroll
+            for (int a = 0; a < TN; ++a) af[a] = *(const bf16x8_t*)(wb + (woff[a] ^ (kk << 6)));
+#pragma unroll
+            for (int b = 0; b < TM; ++b) bfr[b] = *(const bf16x8_t*)(xb + (xoff[b] ^ (kk << 6)));
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] = mfma16(af[a], bfr[b], acc[a][b]);
+        }
+    };
+
+    const int nk = K / BK;
+    stage(0, 0);
+    wait_vm0();
+    __syncthreads();
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        stage((kt + 1) & 1, (kt + 1) * BK);
+        compute(kt & 1);
+        wait_vm0();
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+
+    store_tile<EPI, TM, TN>(acc, ep, M, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "ring" loop: 256 x 256 tile, 8 waves (2 x 4), BK = 32 stages in a 5-slot ring (all 160 KiB of LDS).
+// Rows are 64 B (4 chunks); chunk XOR (3 * ((row>>3)&1)) makes the 16x16x32 fragment reads conflict-free.
+// Weight rows are staged in a permuted order (see store_tile_wide) so that the epilogue stores full lines.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                           int M, int N, int K, int ldx, int ldw, EpiArgs ep) {
+    constexpr int BM = 256, BN = 256, BK = 32, WN = 4, NT = 512;
+    constexpr int TM = 8, TN = 4;                 // per wave: 128 (m) x 64 (n)
+    constexpr int OP_BYTES = 256 * BK * 2;        // 16 KiB per operand per stage
+    constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 32 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tiles_n = N / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (id / tiles_n) * BM;
+    const int n0 = (id % tiles_n) * BN;
+
+    // staging: 1024 chunks per operand per stage, 2 per thread: chunk q -> row q>>2, slot q&3
+    const bf16_t* xsrc[2];
+    const bf16_t* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * NT + tid, row = q >> 2, c = (q & 3) ^ (((row >> 3) & 1) * 3);
+        int grow = m0 + row;
+        grow = grow < M ? grow : M - 1;
+        xsrc[i] = X + (size_t)grow * ldx + c * 8;
+        // LDS row = wave_n*64 + a*16 + r  holds weight row  wave_n*64 + (r>>2)*16 + a*4 + (r&3)
+        const int r = row & 15, a = (row >> 4) & 3;
+        const int wrow = (row & ~63) + (r >> 2) * 16 + a * 4 + (r & 3);
+        wsrc[i] = W + (size_t)(n0 + wrow) * ldw + c * 8;
+    }
+    auto stage = [&](int kt, int slot) {
+        char* xb = smem + slot * STAGE_BYTES;
+        char* wb = xb + OP_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(xsrc[i] + k0, xb + (i * NT + wave * 64) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(wsrc[i] + k0, wb + (i * NT + wave * 64) * 16);
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // fragment offset of this lane inside a 16-row block: row (lane&15), chunk (lane>>4) swizzled
+    const int frow = lane & 15;
+    const int foff = frow * 64 + (((lane >> 4) ^ (((frow >> 3) & 1) * 3)) << 4);
+    const int woff = wn * 64 * 64 + foff;     // wave's first W row * 64 B
+    const int xoff = wm * 128 * 64 + foff;
+
+    // Fragments live in registers one stage ahead of the MFMAs that consume them: while stage kt's 32 MFMAs
+    // issue, stage kt+1's fragments are read from LDS into the registers the retired ones leave behind
+    // (the X fragment of row block b right after its 4 MFMAs; the W fragments into the other half of a
+    // double buffer).  Matrix pipe and LDS pipe therefore overlap instead of alternating.
+    bf16x8_t wf[2][TN];
+    bf16x8_t xf[TM];
+    auto frag_w = [&](int slot, int a) {
+        return *(const bf16x8_t*)(smem + slot * STAGE_BYTES + OP_BYTES + woff + a * 16 * 64);
+    };
+    auto frag_x = [&](int slot, int b) { return *(const bf16x8_t*)(smem + slot * STAGE_BYTES + xoff + b * 16 * 64); };
+
+    // One stage.  P = parity of kt (selects the W-fragment buffer); PREFETCH = stage kt+1 exists, its ring
+    // slot is `next_slot`.
+    auto body = [&](auto parity, auto prefetch, int next_slot) {
+        constexpr int P = decltype(parity)::value;
+        constexpr bool PREFETCH = decltype(prefetch)::value;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) acc[a][b] = mfma16(wf[P][a], xf[b], acc[a][b]);
+            if (PREFETCH) {
+                xf[b] = frag_x(next_slot, b);
+                if (b < TN) wf[P ^ 1][b] = frag_w(next_slot, b);
+            }
+        }
+        if (PREFETCH) {
+            // pin the interleave: 4 MFMAs, then the LDS reads whose registers they freed
+#define VA_GRP(n_reads)                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       \
+    __builtin_amdgcn_sched_group_barrier(0x100, n_reads, 0);
+            VA_GRP(2) VA_GRP(2) VA_GRP(2) VA_GRP(2) VA_GRP(1) VA_GRP(1) VA_GRP(1) VA_GRP(1)
+#undef VA_GRP
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+
+    constexpr int RING = 5;
+    const int nk = K / BK;   // even and >= 4 (checked by the host)
+    stage(0, 0);
+    stage(1, 1);
+    stage(2, 2);
+    stage(3, 3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // stage 0 landed (own loads) ...
+    __builtin_amdgcn_s_barrier();                          // ... and everybody else's
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) xf[b] = frag_x(0, b);
+
+    // At the top of stage kt the loads of stages kt+1..kt+3 are outstanding; vmcnt(8) retires kt+1 (needed
+    // by this stage's prefetch reads) and leaves two stages in flight across the barrier.  The barrier also
+    // tells that every wave has consumed stage kt-1, whose ring slot stage kt+4 then refills.
+    int slot = 0;                                   // ring slot of stage kt
+    auto advance = [&](int sl) { return sl + 1 == RING ? 0 : sl + 1; };
+    auto sync_and_refill = [&](int kt) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 4 < nk) stage(kt + 4, slot == 0 ? RING - 1 : slot - 1);
+    };
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) {     // stages 0 .. nk-5 in pairs (each has three successors in flight)
+        sync_and_refill(kt);
+        body(P0{}, Yes{}, advance(slot));
+        slot = advance(slot);
+        sync_and_refill(kt + 1);
+        body(P1{}, Yes{}, advance(slot));
+        slot = advance(slot);
+    }
+    // tail: stages nk-4 .. nk-1; nothing is issued any more, so the counts step down
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    body(P0{}, Yes{}, advance(slot));
+    slot = advance(slot);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    body(P1{}, Yes{}, advance(slot));
+    slot = advance(slot);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    body(P0{}, Yes{}, advance(slot));
+    body(P1{}, No{}, 0);
+
+    store_tile_wide<EPI, TM>(acc, ep, M, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+int ensure_lds(const void* kern, int bytes, bool* flags) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-            va_set_error("va_gemm_nt: cannot reserve %d bytes of LDS", LDS);
+    if (dev >= 0 && dev < 64 && !flags[dev]) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+            va_set_error("va_gemm_nt: cannot reserve %d bytes of LDS", bytes);
             return VA_ERR_LAUNCH;
         }
-        attr_set[dev] = true;
+        flags[dev] = true;
     }
+    return VA_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+int launch_pair(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
+                hipStream_t stream) {
+    constexpr int LDS = 2 * (BM + BN) * 64 * 2;
+    auto kern = gemm_nt_pair_kernel<BM, BN, WM, WN, EPI>;
+    static bool flags[64] = {};
+    if (int e = ensure_lds((const void*)kern, LDS, flags)) return e;
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), LDS, stream, X, W, M, N, K, ldx, ldw, ep);
     VA_CHECK_LAUNCH("va_gemm_nt");
@@ -192,10 +438,24 @@ int launch_cfg(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, i
 }
 
 template <int EPI>
+int launch_ring(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
+                hipStream_t stream) {
+    constexpr int LDS = 5 * 2 * 256 * 32 * 2;     // the whole 160 KiB of a CU
+    auto kern = gemm_nt_ring_kernel<EPI>;
+    static bool flags[64] = {};
+    if (int e = ensure_lds((const void*)kern, LDS, flags)) return e;
+    const int tiles = ((M + 255) / 256) * (N / 256);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, X, W, M, N, K, ldx, ldw, ep);
+    VA_CHECK_LAUNCH("va_gemm_nt");
+    return VA_OK;
+}
+
+template <int EPI>
 int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
                hipStream_t stream) {
-    if (tile == 256) return launch_cfg<256, 256, 2, 4, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
-    return launch_cfg<128, 128, 2, 2, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (tile == 256) return launch_ring<EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (tile == 1256) return launch_pair<256, 256, 2, 4, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
+    return launch_pair<128, 128, 2, 2, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
 }
 
 }  // namespace
@@ -212,9 +472,9 @@ extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, in
     VA_CHECK_ARG(ldx % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "va_gemm_nt: leading dimensions must keep 16-byte alignment");
     VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) % 16 == 0, "va_gemm_nt: operands must be 16-byte aligned");
     VA_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "va_gemm_nt: problem too large");
-    if (tile == 0) tile = (N % 256 == 0 && M >= 2048) ? 256 : 128;
-    VA_CHECK_ARG(tile == 128 || (tile == 256 && N % 256 == 0), "va_gemm_nt: tile %d not usable with N=%lld", tile,
-                 (long long)N);
+    if (tile == 0) tile = (N % 256 == 0 && M >= 2048 && K >= 128) ? 256 : 128;
+    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256) && N % 256 == 0 && K >= 128),
+                 "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc};
     const bf16_t* X = (const bf16_t*)x;
     const bf16_t* W = (const bf16_t*)w;
