@@ -48,7 +48,8 @@ int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, int64_t K, in
                int64_t ldc, int tile, va_stream_t stream);
 
 /* dw[N,K] (f32) += dy[M,N]^T * x[M,K]: the weight-gradient half of nn.Linear's backward (autograd of
- * swm:296, 334, 698-701, 102).  bf16 operands, split over M in `split_k` slices (0 = choose) that are
+ * swm:296, 334, 698-701, 102).  bf16 operands, split over M in `split_k` slices (0 = choose; negative =
+ * |split_k| slices on the small-tile kernel) that are
  * combined with f32 atomic adds, so `dw` must hold the value to accumulate onto (zeros for a fresh
  * gradient).  If dbias != NULL, dbias[N] (f32) += column sums of dy (the bias gradient) in the same pass.
  * N % 128 == 0, K % 128 == 0; any M. */

@@ -104,7 +104,9 @@ def test_gemm_nt_rejects_bad_shapes(ops, dev):
 
 # ------------------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("M,N,K,split", [(8, 1024, 1024, 0), (64, 128, 128, 1), (1000, 3072, 1024, 0),
-                                         (4096 + 13, 128, 256, 1), (4096 + 13, 128, 256, 7), (8192, 1024, 4096, 0)])
+                                         (4096 + 13, 128, 256, 1), (4096 + 13, 128, 256, 7), (8192, 1024, 4096, 0),
+                                         (4096 + 13, 256, 256, 0), (4096 + 13, 256, 512, 3), (129, 256, 256, 1),
+                                         (128, 256, 256, 1), (2048, 1024, 1536, 0), (2048, 1024, 1024, -4)])
 def test_gemm_tn(ops, dev, M, N, K, split):
     dy = rnd((M, N), dev, 7, dtype=BF16)
     x = rnd((M, K), dev, 8, dtype=BF16)
@@ -130,6 +132,22 @@ def test_gemm_tn_layout(ops, dev):
     ref = torch.zeros(N, K, device=dev)
     ref[perm] = x.float()
     assert torch.equal(dw, ref)
+
+
+def test_gemm_tn_ring_layout(ops, dev):
+    """Same one-hot check on the 256x256-tile kernel (M = 4 stages of 32 rows)."""
+    M, N, K = 128, 256, 512
+    dy = torch.zeros(M, N, dtype=BF16, device=dev)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:M].to(dev)
+    dy[torch.arange(M, device=dev), perm] = 1
+    x = rnd((M, K), dev, 9, dtype=BF16)
+    dw = torch.zeros(N, K, dtype=F32, device=dev)
+    db = torch.zeros(N, dtype=F32, device=dev)
+    ops.gemm_tn_accum(dy, x, dw, dbias=db, split_k=1)
+    ref = torch.zeros(N, K, device=dev)
+    ref[perm] = x.float()
+    assert torch.equal(dw, ref)
+    assert torch.equal(db, dy.float().sum(0))
 
 
 def test_colsum(ops, dev):

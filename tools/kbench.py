@@ -31,7 +31,7 @@ for name, (Nn, K) in {"qkv": (3 * D, D), "out": (D, D), "fc1": (4 * D, D), "fc2"
         print(f"gemm_nt {name} tile{tile}: {t*1e3:.3f} ms  {2*M*Nn*K/t/1e12:.1f} TF/s", flush=True)
     dw = torch.zeros(Nn, K, dtype=F32, device=dev)
     dy = rnd((M, Nn))
-    for split in (0, 2, 4, 8, 16):
+    for split in (0, 2, 4, 8, 16, -6):
         t = timeit(lambda: ops.gemm_tn_accum(dy, a, dw, split_k=split))
         print(f"gemm_tn {name} split{split}: {t*1e3:.3f} ms  {2*M*Nn*K/t/1e12:.1f} TF/s", flush=True)
     del dw, dy, out

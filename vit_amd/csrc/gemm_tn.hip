@@ -16,6 +16,7 @@
 //   * the bias gradient (column sums of dY) is optionally fused: one extra MFMA against an all-ones
 //     operand reuses the dY^T fragments that are in registers anyway, instead of a second pass over dY.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -174,6 +175,206 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large-problem variant: 256(n) x 256(k) tile, 8 waves (2 x 4, each 128 x 64 as 4 x 2 MFMA 32x32x16 tiles),
+// contraction in 32-row stages through a 5-slot LDS ring (all 160 KiB) with counted vmcnt waits, and MFMA
+// fragments read from LDS one k-step ahead of their use (see gemm_nt.hip, ring loop, for the protocol).
+// Rows of a staged tile are 512 B (32 chunks); chunk XOR ((row&3)<<2) keeps the transposed reads
+// conflict-free.  One workgroup per CU, so the grid is sized to about one workgroup per CU by the M split.
+// ------------------------------------------------------------------------------------------------
+constexpr int RBM = 32;                       // contraction rows per stage
+constexpr int ROP_BYTES = RBM * 256 * 2;      // 16 KiB per operand per stage
+constexpr int RSTAGE_BYTES = 2 * ROP_BYTES;
+constexpr int RRING = 5;
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
+                                                           int M, int N, int K, int lddy, int ldx,
+                                                           float* __restrict__ DW, int lddw, int m_per_slice,
+                                                           float* __restrict__ DBIAS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wk = wave & 3;
+
+    // Work ids are slice-major, and the workgroups that share an XCD take one contiguous run of them: the
+    // ~32 workgroups resident on an XCD then sweep the SAME rows of dY and X (one M slice) for a compact
+    // block of output tiles, so each staged row segment is fetched from HBM once and reused out of that
+    // XCD's L2 by every tile that needs it.
+    const int tiles_k = K / 256;
+    const int tiles = (N / 256) * tiles_k;
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int id = work % tiles;
+    const int n0 = (id / tiles_k) * 256;
+    const int k0 = (id % tiles_k) * 256;
+    const int m_begin = (work / tiles) * m_per_slice;
+    int m_end = m_begin + m_per_slice;
+    m_end = m_end < M ? m_end : M;
+    const int nk = (m_end - m_begin + RBM - 1) / RBM;            // >= 4 (host guarantees)
+    const int tail_valid = (m_end - m_begin) - (nk - 1) * RBM;   // rows valid in the last stage (1..32)
+
+    // staging: 1024 chunks per operand per stage, 2 per thread: chunk q -> row q>>5, slot q&31
+    int srow[2], scol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        srow[i] = q >> 5;
+        scol[i] = ((q & 31) ^ ((srow[i] & 3) << 2)) * 8;
+    }
+    auto stage = [&](int kt, int slot) {
+        char* yb = smem + slot * RSTAGE_BYTES;
+        char* xb = yb + ROP_BYTES;
+        const int mb = m_begin + kt * RBM;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = mb + srow[i];
+            m = m < M ? m : M - 1;
+            glds16(DY + (size_t)m * lddy + n0 + scol[i], yb + (i * 512 + wave * 64) * 16);
+            glds16(X + (size_t)m * ldx + k0 + scol[i], xb + (i * 512 + wave * 64) * 16);
+        }
+    };
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const bool do_bias = HAS_BIAS && (id % tiles_k == 0);
+    f32x16_t bacc;                  // wave (wn, wk) sums the 32 columns of n-block a = wk
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+
+    const int gi = lane >> 4, cg = gi & 1, h = gi >> 1, q4 = (lane & 15) >> 2, p = lane & 3;
+    auto tr_off = [&](int colbase) {
+        const int row = 8 * h + q4;
+        const int chunk = ((colbase + 16 * cg + 4 * p) >> 3) ^ ((row & 3) << 2);
+        return row * 512 + (chunk << 4) + (p & 1) * 8;
+    };
+    int yoff[4], xoff[2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) yoff[a] = tr_off(wn * 128 + a * 32);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) xoff[b] = ROP_BYTES + tr_off(wk * 64 + b * 32);
+
+    // fragments of k-step s (16 rows) of the stage in `slot`
+    auto frag = [&](int slot, int s, int off) {
+        const char* ptr = smem + slot * RSTAGE_BYTES + off + s * 16 * 512;
+        return join_tr(lds_read_tr16(ptr), lds_read_tr16(ptr + 4 * 512));
+    };
+    bf16x8_t fa[2][4], fb[2][2];
+
+    // zero rows [valid, 32) of both operand tiles of a slot (ragged end of M)
+    auto zero_tail = [&](int slot, int valid) {
+        char* base = smem + slot * RSTAGE_BYTES;
+        for (int c = tid; c < 2 * RBM * 32; c += 512) {
+            const int r = (c >> 5) & (RBM - 1);
+            if (r >= valid) *(u32x4_t*)(base + c * 16) = (u32x4_t){0u, 0u, 0u, 0u};
+        }
+    };
+
+    // one k-step: 8 MFMAs on fragment set S while the next k-step's fragments land in set S^1
+    auto kstep = [&](auto set, auto prefetch, int nslot, int ns) {
+        constexpr int S = decltype(set)::value;
+        constexpr bool PREFETCH = decltype(prefetch)::value;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(fa[S][a], fb[S][b], acc[a][b]);
+            if (PREFETCH) {
+                fa[S ^ 1][a] = frag(nslot, ns, yoff[a]);
+                if (a < 2) fb[S ^ 1][a] = frag(nslot, ns, xoff[a]);
+            }
+        }
+        if (HAS_BIAS) {   // every k-tile does the (cheap) extra MFMA; only k-tile 0 publishes it
+            const u32x4_t f0 = __builtin_bit_cast(u32x4_t, fa[S][0]), f1 = __builtin_bit_cast(u32x4_t, fa[S][1]);
+            const u32x4_t f2 = __builtin_bit_cast(u32x4_t, fa[S][2]), f3 = __builtin_bit_cast(u32x4_t, fa[S][3]);
+            u32x4_t mine;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mine[j] = wk == 0 ? f0[j] : (wk == 1 ? f1[j] : (wk == 2 ? f2[j] : f3[j]));
+            bacc = mfma32(__builtin_bit_cast(bf16x8_t, mine), ones, bacc);
+        }
+        if (PREFETCH) {
+#define VA_GRP(n_reads)                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       \
+    __builtin_amdgcn_sched_group_barrier(0x100, n_reads, 0);
+            VA_GRP(4) VA_GRP(4) VA_GRP(2) VA_GRP(2)
+#undef VA_GRP
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    auto advance = [&](int sl) { return sl + 1 == RRING ? 0 : sl + 1; };
+
+    stage(0, 0);
+    stage(1, 1);
+    stage(2, 2);
+    stage(3, 3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < 4; ++a) fa[0][a] = frag(0, 0, yoff[a]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) fb[0][b] = frag(0, 0, xoff[b]);
+
+    int slot = 0;
+    int kt = 0;
+    for (; kt + 4 < nk; ++kt) {           // stages with three successors in flight
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage(kt + 4, slot == 0 ? RRING - 1 : slot - 1);
+        kstep(S0{}, Yes{}, slot, 1);
+        kstep(S1{}, Yes{}, advance(slot), 0);
+        slot = advance(slot);
+    }
+    // tail: stages nk-4 .. nk-1
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    kstep(S0{}, Yes{}, slot, 1);
+    kstep(S1{}, Yes{}, advance(slot), 0);
+    slot = advance(slot); ++kt;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    kstep(S0{}, Yes{}, slot, 1);
+    kstep(S1{}, Yes{}, advance(slot), 0);
+    slot = advance(slot); ++kt;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tail_valid < RBM) {               // uniform: the last stage has landed everywhere, blank its unused rows
+        zero_tail(advance(slot), tail_valid);
+        __syncthreads();
+    }
+    kstep(S0{}, Yes{}, slot, 1);
+    kstep(S1{}, Yes{}, advance(slot), 0);
+    slot = advance(slot); ++kt;
+    kstep(S0{}, Yes{}, slot, 1);
+    kstep(S1{}, No{}, 0, 0);
+
+    const int hh = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float* base = DW + (size_t)(n0 + wn * 128 + a * 32) * lddw + k0 + wk * 64 + b * 32 + col;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) unsafeAtomicAdd(base + (size_t)acc32_row(i, hh) * lddw, acc[a][b][i]);
+        }
+    if (do_bias && col == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) unsafeAtomicAdd(DBIAS + n0 + wn * 128 + wk * 32 + acc32_row(i, hh), bacc[i]);
+    }
+}
+
 }  // namespace
 
 extern "C" int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_t N, int64_t K, int64_t lddy,
@@ -187,6 +388,48 @@ extern "C" int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_
     VA_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0, "va_gemm_tn_accum: leading dimensions must keep 16-byte alignment");
     VA_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x) % 16 == 0 && (uintptr_t)dw % 4 == 0, "va_gemm_tn_accum: misaligned operand");
     VA_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "va_gemm_tn_accum: problem too large");
+    // ---- large problems: 256 x 256 tiles, about one workgroup per CU
+    if (N % 256 == 0 && K % 256 == 0 && split_k >= 0) {
+        const int rtiles = (int)((N / 256) * (K / 256));
+        const int64_t rstages = (M + RBM - 1) / RBM;
+        int split = split_k;
+        if (split == 0) {
+            split = rtiles >= 256 ? 1 : 256 / rtiles;
+            if (split < 1) split = 1;
+        }
+        int64_t per = (rstages + split - 1) / split;          // stages per slice
+        if (per < 4) per = 4;
+        const int64_t m_per = per * RBM;
+        const int slices = (int)((M + m_per - 1) / m_per);
+        const int64_t last = M - (int64_t)(slices - 1) * m_per;   // rows of the last slice
+        if (last >= 4 * RBM - (RBM - 1) && (last + RBM - 1) / RBM >= 4) {
+            static bool ring_attr[2][64] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const int hb = dbias != nullptr;
+            const void* kern = hb ? (const void*)gemm_tn_ring_kernel<true> : (const void*)gemm_tn_ring_kernel<false>;
+            if (dev >= 0 && dev < 64 && !ring_attr[hb][dev]) {
+                if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, RRING * RSTAGE_BYTES) !=
+                    hipSuccess) {
+                    va_set_error("va_gemm_tn_accum: cannot reserve %d bytes of LDS", RRING * RSTAGE_BYTES);
+                    return VA_ERR_LAUNCH;
+                }
+                ring_attr[hb][dev] = true;
+            }
+            if (hb)
+                hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, dim3(rtiles * slices), dim3(512), RRING * RSTAGE_BYTES,
+                                   stream, (const bf16_t*)dy, (const bf16_t*)x, (int)M, (int)N, (int)K, (int)lddy,
+                                   (int)ldx, dw, (int)lddw, (int)m_per, dbias);
+            else
+                hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, dim3(rtiles * slices), dim3(512), RRING * RSTAGE_BYTES,
+                                   stream, (const bf16_t*)dy, (const bf16_t*)x, (int)M, (int)N, (int)K, (int)lddy,
+                                   (int)ldx, dw, (int)lddw, (int)m_per, dbias);
+            VA_CHECK_LAUNCH("va_gemm_tn_accum");
+            return VA_OK;
+        }
+    }
+    if (split_k < 0) split_k = -split_k;      // negative: force the 128 x 128 kernel with |split_k| slices
+
     const int tiles = (int)((N / 128) * (K / 128));
     const int steps = (int)((M + TBM - 1) / TBM);
     if (split_k <= 0) {
