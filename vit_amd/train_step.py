@@ -1,0 +1,117 @@
+"""Training-step harnesses around the encoder.
+
+`stage1_losses` / `stage1_step` restate the step of the reference's stage-1 loop
+(stage1_surgvu_pretraining.py:418-470; frozen-encoder variant stage1_vjepa2_finetuning.py:281-339):
+order classification on a shuffled clip, symmetric InfoNCE between a clip and its augmentation, and the
+masked-mean denoising term on a no-grad pass, `loss = L_t + L_c + lambda * L_m`, global-norm clip 1.0, AdamW.
+The heads are tiny (B x 1024 MLPs) and stay ordinary torch modules; the encoder passes are the HIP path.
+
+`jepa_latent_step` is the composite that exercises the token-gather, L1 and EMA kernels at full size; the
+reference has no such objective (its "JEPA" is the three terms above).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .ddp import all_gather_with_grad
+from .masking import StructuredTemporalMasking
+
+
+class Stage1Heads(nn.Module):
+    """The three heads the stage-1 loop builds on top of the encoder (s1:362-383), same layer layout."""
+
+    def __init__(self, dim: int = 1024, use_mask_aux: bool = True):
+        super().__init__()
+        self.temporal_classifier = nn.Sequential(nn.Linear(dim, dim // 2), nn.ReLU(), nn.Dropout(0.1), nn.Linear(dim // 2, 2))
+        self.contrastive_proj = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(), nn.Linear(dim, 128))
+        self.denoise_head = (nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, dim), nn.GELU(), nn.Linear(dim, dim))
+                             if use_mask_aux else None)
+
+
+def stage1_losses(model, heads: Stage1Heads, video, video_aug, shuffled_video, order_label,
+                  lambda_mask: float = 0.1, temperature: float = 0.07, fuse_views: bool = True,
+                  encoder_grad: bool = True, group: Optional[dist.ProcessGroup] = None):
+    """Returns (total, (temporal, contrastive, mask)).  `fuse_views` runs the three gradient-carrying views
+    as ONE encoder pass over 3B clips (clips are independent, so the result is identical and every weight
+    is read once instead of three times).  With `group` set, the InfoNCE negatives span the global batch."""
+    B = video.shape[0]
+    with torch.set_grad_enabled(encoder_grad and torch.is_grad_enabled()):
+        if fuse_views:
+            feats = model.encode_video(torch.cat([shuffled_video, video, video_aug], dim=0)).mean(dim=1)
+            f_shuf, f_orig, f_aug = feats[:B], feats[B:2 * B], feats[2 * B:]
+        else:
+            f_shuf = model.encode_video(shuffled_video).mean(dim=1)
+            f_orig = model.encode_video(video).mean(dim=1)
+            f_aug = model.encode_video(video_aug).mean(dim=1)
+    l_t = F.cross_entropy(heads.temporal_classifier(f_shuf), order_label)
+
+    z1 = F.normalize(heads.contrastive_proj(f_orig), dim=1)
+    z2 = F.normalize(heads.contrastive_proj(f_aug), dim=1)
+    world = 1
+    if group is not None or (dist.is_initialized() and dist.get_world_size() > 1):
+        world = dist.get_world_size(group)
+        z1, z2 = all_gather_with_grad(z1, group), all_gather_with_grad(z2, group)
+    labels = torch.arange(z1.shape[0], device=z1.device)
+    l_c = 0.5 * (F.cross_entropy(z1 @ z2.t() / temperature, labels) + F.cross_entropy(z2 @ z1.t() / temperature, labels))
+
+    l_m = torch.zeros((), device=video.device)
+    if heads.denoise_head is not None:
+        with torch.no_grad():
+            tokens = model.encode_video(video)
+            Tp = model.encoder.tubelet_embed.num_temporal_patches
+            masked, mask = StructuredTemporalMasking.future_masking(tokens, Tp, 0.5)
+        keep = ~mask
+        pooled = (masked * keep.unsqueeze(-1)).sum(dim=1) / keep.sum(dim=1, keepdim=True).clamp_min(1)
+        l_m = F.mse_loss(heads.denoise_head(pooled), tokens.mean(dim=1))
+    # the gathered InfoNCE term is the same number on every rank while gradients are averaged over ranks
+    total = l_t + world * l_c + lambda_mask * l_m if world > 1 else l_t + l_c + lambda_mask * l_m
+    return total, (l_t.detach(), l_c.detach(), l_m.detach())
+
+
+def stage1_step(model, heads: Stage1Heads, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor],
+                max_norm: float = 1.0, **kw) -> Tuple[float, Tuple[torch.Tensor, ...]]:
+    optimizer.zero_grad(set_to_none=True)
+    loss, parts = stage1_losses(model, heads, batch["video"], batch["video_augmented"], batch["shuffled_video"],
+                                batch["order_label"].long(), **kw)
+    loss.backward()
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+    optimizer.step()
+    return float(loss.detach()), parts
+
+
+def jepa_latent_step(encoder, target_encoder, video: torch.Tensor, target_idx: torch.Tensor,
+                     momentum: float = 0.996, target_flat=None, online_flat=None):
+    """loss = mean | gather(encoder(video)) - gather(target_encoder(video)) | over the target tokens, backward
+    into `encoder`, then (if the flat parameter sets are given) target <- m*target + (1-m)*online."""
+    from .jepa import ema_update_, l1_latent_loss
+    with torch.no_grad():
+        tgt = ops.token_gather(target_encoder(video).contiguous(), target_idx)
+    z = encoder(video)
+    pred = _TokenGather.apply(z, target_idx)
+    loss = l1_latent_loss(pred, tgt)
+    loss.backward()
+    if target_flat is not None and online_flat is not None:
+        ema_update_(target_flat, online_flat, momentum, target_encoder)
+    return loss.detach()
+
+
+class _TokenGather(torch.autograd.Function):
+    """Row gather with its scatter as the backward (both single kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = x.shape[1]
+        return ops.token_gather(x.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return ops.token_scatter(g.contiguous(), idx, ctx.n), None
