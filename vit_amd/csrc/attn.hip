@@ -93,8 +93,8 @@ VA_DEVINL void store_rows(const f32x16_t (&acc)[HD / 32], float mul, bf16_t* out
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int HD, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE2, int N, int H, int64_t ld, int64_t ldo,
                                                        float c) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) st[kb] = mfma32(row_frag<HD>(kt, kb * 32, ks, lane), qf[ks], st[kb]);
         }
-        if (t == nt - 1 && (N % TILE_ROWS) != 0) {
+        if (RAGGED && t == nt - 1) {   // RAGGED <=> N % 64 != 0: only that build carries the selects
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------
 // dQ pass: query-stationary, streams K and V.
 // ------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int HD, bool RAGGED>
+__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
                                                           const float* __restrict__ LSE2,
                                                           const float* __restrict__ DELTA, bf16_t* __restrict__ DQ,
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                 s = mfma32(row_frag<HD>(kt, kb * 32, ks, lane), qf[ks], s);
                 dp = mfma32(row_frag<HD>(vt, kb * 32, ks, lane), dof[ks], dp);
             }
-            const bool ragged = (t == nt - 1) && (N % TILE_ROWS) != 0;
+            const bool ragged = RAGGED && (t == nt - 1);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float p = fast_exp2(fmaf(s[i], c, -lse));
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------------------
 // dK/dV pass: key-stationary, streams Q and dO (plus the per-query lse2 and delta).
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, bool RAGGED>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
                                                            const float* __restrict__ LSE2,
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
                 dp = mfma32(row_frag<HD>(dot, qb * 32, ks, lane), vf[ks], dp);
             }
             f32x16_t pr;
-            const bool ragged = (t == nt - 1) && (N % TILE_ROWS) != 0;
+            const bool ragged = RAGGED && (t == nt - 1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4_t lv = *(const f32x4_t*)(lse_t + qb * 32 + 8 * g + 4 * h);
@@ -435,11 +435,16 @@ template <int HD>
 int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
                int64_t ld, int64_t ldo, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * TILE_ROWS * HD * 2;
-    static bool flags[64] = {};
-    if (int e = set_lds(attn_fwd_kernel<HD>, LDS, flags, "va_attn_fwd")) return e;
+    static bool flags[2][64] = {};
     const float c = 1.4426950408889634f / sqrtf((float)HD);
-    hipLaunchKernelGGL(attn_fwd_kernel<HD>, dim3((N + 127) / 128, B * H), dim3(256), LDS, stream, q, k, v, o, lse2, N, H,
-                       ld, ldo, c);
+    const dim3 grid((N + 127) / 128, B * H);
+    if (N % TILE_ROWS) {
+        if (int e = set_lds(attn_fwd_kernel<HD, true>, LDS, flags[1], "va_attn_fwd")) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), LDS, stream, q, k, v, o, lse2, N, H, ld, ldo, c);
+    } else {
+        if (int e = set_lds(attn_fwd_kernel<HD, false>, LDS, flags[0], "va_attn_fwd")) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), LDS, stream, q, k, v, o, lse2, N, H, ld, ldo, c);
+    }
     VA_CHECK_LAUNCH("va_attn_fwd");
     return VA_OK;
 }
@@ -450,9 +455,15 @@ int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* 
                int64_t ldo, int64_t lddq, hipStream_t stream) {
     constexpr int LDS_DQ = 2 * 2 * TILE_ROWS * HD * 2;
     constexpr int LDS_DKV = 2 * (2 * TILE_ROWS * HD * 2 + 2 * TILE_ROWS * 4);
-    static bool f1[64] = {}, f2[64] = {};
-    if (int e = set_lds(attn_bwd_dq_kernel<HD>, LDS_DQ, f1, "va_attn_bwd")) return e;
-    if (int e = set_lds(attn_bwd_dkv_kernel<HD>, LDS_DKV, f2, "va_attn_bwd")) return e;
+    static bool f1[2][64] = {}, f2[2][64] = {};
+    const bool ragged = (N % TILE_ROWS) != 0;
+    if (ragged) {
+        if (int e = set_lds(attn_bwd_dq_kernel<HD, true>, LDS_DQ, f1[1], "va_attn_bwd")) return e;
+        if (int e = set_lds(attn_bwd_dkv_kernel<HD, true>, LDS_DKV, f2[1], "va_attn_bwd")) return e;
+    } else {
+        if (int e = set_lds(attn_bwd_dq_kernel<HD, false>, LDS_DQ, f1[0], "va_attn_bwd")) return e;
+        if (int e = set_lds(attn_bwd_dkv_kernel<HD, false>, LDS_DKV, f2[0], "va_attn_bwd")) return e;
+    }
     const float scale = 1.0f / sqrtf((float)HD);
     const float c = 1.4426950408889634f * scale;
     const int64_t rows = (int64_t)B * N;
@@ -460,11 +471,20 @@ int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* 
     hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, o, d_o,
                        delta, rows, N, H, ldo);
     VA_CHECK_LAUNCH("va_attn_bwd(delta)");
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, dim3((N + 127) / 128, B * H), dim3(256), LDS_DQ, stream, q, k, v, d_o,
-                       lse2, delta, dq, N, H, ld, ldo, lddq, c, scale);
+    const dim3 grid((N + 127) / 128, B * H);
+    if (ragged)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), grid, dim3(256), LDS_DQ, stream, q, k, v, d_o, lse2, delta, dq,
+                           N, H, ld, ldo, lddq, c, scale);
+    else
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), grid, dim3(256), LDS_DQ, stream, q, k, v, d_o, lse2, delta, dq,
+                           N, H, ld, ldo, lddq, c, scale);
     VA_CHECK_LAUNCH("va_attn_bwd(dq)");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HD>, dim3((N + 127) / 128, B * H), dim3(256), LDS_DKV, stream, q, k, v, d_o,
-                       lse2, delta, dk, dv, N, H, ld, ldo, lddq, c, scale);
+    if (ragged)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, lse2, delta,
+                           dk, dv, N, H, ld, ldo, lddq, c, scale);
+    else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, lse2, delta,
+                           dk, dv, N, H, ld, ldo, lddq, c, scale);
     VA_CHECK_LAUNCH("va_attn_bwd(dkv)");
     return VA_OK;
 }

@@ -25,8 +25,12 @@ VA_DEVINL bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+// Two f32 -> one dword of two bf16 (lo in bits 0-15): a single v_cvt_pk_bf16_f32.
 VA_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // ---- LDS / global helpers ----------------------------------------------
