@@ -263,7 +263,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pair_kernel(const bf16_t*
 // Rows are 64 B (4 chunks); chunk XOR (3 * ((row>>3)&1)) makes the 16x16x32 fragment reads conflict-free.
 // Weight rows are staged in a permuted order (see store_tile_wide) so that the epilogue stores full lines.
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, bool PAIRED>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                            int M, int N, int K, int ldx, int ldw, EpiArgs ep) {
     constexpr int BM = 256, BN = 256, BK = 32, WN = 4, NT = 512;
@@ -359,54 +359,99 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
 
     constexpr int RING = 5;
     const int nk = K / BK;   // even and >= 4 (checked by the host)
-    stage(0, 0);
-    stage(1, 1);
-    stage(2, 2);
-    stage(3, 3);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // stage 0 landed (own loads) ...
-    __builtin_amdgcn_s_barrier();                          // ... and everybody else's
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
-#pragma unroll
-    for (int b = 0; b < TM; ++b) xf[b] = frag_x(0, b);
-
-    // At the top of stage kt the loads of stages kt+1..kt+3 are outstanding; vmcnt(8) retires kt+1 (needed
-    // by this stage's prefetch reads) and leaves two stages in flight across the barrier.  The barrier also
-    // tells that every wave has consumed stage kt-1, whose ring slot stage kt+4 then refills.
-    int slot = 0;                                   // ring slot of stage kt
     auto advance = [&](int sl) { return sl + 1 == RING ? 0 : sl + 1; };
-    auto sync_and_refill = [&](int kt) {
+    if (PAIRED) {
+        // Loads are issued for TWO consecutive stages at a time, row by row, so that the two 64-byte halves
+        // of every 128-byte line are requested back to back (one L2 request instead of two).  Pairs are
+        // issued at the top of odd stages, into the two slots consumed last; the pair issued at stage j is
+        // needed at stage j+2, so one pair (64 KiB) is in flight while two stages compute, and there is one
+        // barrier per two stages.
+        auto stage2 = [&](int kt, int slot_a, int slot_b) {
+            char* xa = smem + slot_a * STAGE_BYTES;
+            char* xb = smem + slot_b * STAGE_BYTES;
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                glds16(xsrc[i] + k0, xa + (i * NT + wave * 64) * 16);
+                glds16(xsrc[i] + k0 + BK, xb + (i * NT + wave * 64) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                glds16(wsrc[i] + k0, xa + OP_BYTES + (i * NT + wave * 64) * 16);
+                glds16(wsrc[i] + k0 + BK, xb + OP_BYTES + (i * NT + wave * 64) * 16);
+            }
+        };
+        stage2(0, 0, 1);
+        stage2(2, 2, 3);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // pair (0,1) landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) xf[b] = frag_x(0, b);
+        body(P0{}, Yes{}, 1);                                 // stage 0
+        int slot = 1;                                         // slot of stage j
+        for (int j = 1; j + 2 < nk; j += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pair (j+1, j+2) landed
+            __builtin_amdgcn_s_barrier();                      // ... everywhere; stages j-2, j-1 are consumed
+            asm volatile("" ::: "memory");
+            const int s1 = advance(slot), s2 = advance(s1), s3 = advance(s2), s4 = advance(s3);
+            if (j + 4 < nk) stage2(j + 3, s3, s4);
+            body(P1{}, Yes{}, s1);                            // stage j   (prefetches j+1)
+            body(P0{}, Yes{}, s2);                            // stage j+1 (prefetches j+2)
+            slot = s2;
+        }
+        body(P1{}, No{}, 0);                                  // stage nk-1
+    } else {
+        stage(0, 0);
+        stage(1, 1);
+        stage(2, 2);
+        stage(3, 3);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // stage 0 landed (own loads) ...
+        __builtin_amdgcn_s_barrier();                          // ... and everybody else's
+        asm volatile("" ::: "memory");
+    #pragma unroll
+        for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
+    #pragma unroll
+        for (int b = 0; b < TM; ++b) xf[b] = frag_x(0, b);
+
+        // At the top of stage kt the loads of stages kt+1..kt+3 are outstanding; vmcnt(8) retires kt+1 (needed
+        // by this stage's prefetch reads) and leaves two stages in flight across the barrier.  The barrier also
+        // tells that every wave has consumed stage kt-1, whose ring slot stage kt+4 then refills.
+        int slot = 0;                                   // ring slot of stage kt
+        auto sync_and_refill = [&](int kt) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 4 < nk) stage(kt + 4, slot == 0 ? RING - 1 : slot - 1);
+        };
+        int kt = 0;
+        for (; kt + 4 < nk; kt += 2) {     // stages 0 .. nk-5 in pairs (each has three successors in flight)
+            sync_and_refill(kt);
+            body(P0{}, Yes{}, advance(slot));
+            slot = advance(slot);
+            sync_and_refill(kt + 1);
+            body(P1{}, Yes{}, advance(slot));
+            slot = advance(slot);
+        }
+        // tail: stages nk-4 .. nk-1; nothing is issued any more, so the counts step down
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 4 < nk) stage(kt + 4, slot == 0 ? RING - 1 : slot - 1);
-    };
-    int kt = 0;
-    for (; kt + 4 < nk; kt += 2) {     // stages 0 .. nk-5 in pairs (each has three successors in flight)
-        sync_and_refill(kt);
         body(P0{}, Yes{}, advance(slot));
         slot = advance(slot);
-        sync_and_refill(kt + 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         body(P1{}, Yes{}, advance(slot));
         slot = advance(slot);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        body(P0{}, Yes{}, advance(slot));
+        body(P1{}, No{}, 0);
     }
-    // tail: stages nk-4 .. nk-1; nothing is issued any more, so the counts step down
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    body(P0{}, Yes{}, advance(slot));
-    slot = advance(slot);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    body(P1{}, Yes{}, advance(slot));
-    slot = advance(slot);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    body(P0{}, Yes{}, advance(slot));
-    body(P1{}, No{}, 0);
 
     store_tile_wide<EPI, TM>(acc, ep, M, m0 + wm * 128, n0 + wn * 64, lane);
 }
@@ -437,11 +482,11 @@ int launch_pair(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
     return VA_OK;
 }
 
-template <int EPI>
+template <int EPI, bool PAIRED>
 int launch_ring(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
                 hipStream_t stream) {
     constexpr int LDS = 5 * 2 * 256 * 32 * 2;     // the whole 160 KiB of a CU
-    auto kern = gemm_nt_ring_kernel<EPI>;
+    auto kern = gemm_nt_ring_kernel<EPI, PAIRED>;
     static bool flags[64] = {};
     if (int e = ensure_lds((const void*)kern, LDS, flags)) return e;
     const int tiles = ((M + 255) / 256) * (N / 256);
@@ -453,7 +498,8 @@ int launch_ring(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
 template <int EPI>
 int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
                hipStream_t stream) {
-    if (tile == 256) return launch_ring<EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (tile == 256) return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (tile == 2256) return launch_ring<EPI, false>(X, W, M, N, K, ldx, ldw, ep, stream);
     if (tile == 1256) return launch_pair<256, 256, 2, 4, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
     return launch_pair<128, 128, 2, 2, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
 }
@@ -473,7 +519,7 @@ extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, in
     VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) % 16 == 0, "va_gemm_nt: operands must be 16-byte aligned");
     VA_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "va_gemm_nt: problem too large");
     if (tile == 0) tile = (N % 256 == 0 && M >= 2048 && K >= 128) ? 256 : 128;
-    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256) && N % 256 == 0 && K >= 128),
+    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256) && N % 256 == 0 && K >= 128),
                  "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc};
     const bf16_t* X = (const bf16_t*)x;

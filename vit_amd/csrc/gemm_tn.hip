@@ -187,11 +187,10 @@ constexpr int ROP_BYTES = RBM * 256 * 2;      // 16 KiB per operand per stage
 constexpr int RSTAGE_BYTES = 2 * ROP_BYTES;
 constexpr int RRING = 5;
 
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
-                                                           int M, int N, int K, int lddy, int ldx,
-                                                           float* __restrict__ DW, int lddw, int m_per_slice,
-                                                           float* __restrict__ DBIAS) {
+template <bool DO_BIAS>
+VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
+                                  int M, int N, int K, int lddy, int ldx, float* __restrict__ DW, int lddw,
+                                  int m_per_slice, float* __restrict__ DBIAS, int work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,7 +202,6 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
     // XCD's L2 by every tile that needs it.
     const int tiles_k = K / 256;
     const int tiles = (N / 256) * tiles_k;
-    const int work = xcd_remap(blockIdx.x, gridDim.x);
     const int id = work % tiles;
     const int n0 = (id / tiles_k) * 256;
     const int k0 = (id % tiles_k) * 256;
@@ -242,7 +240,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    const bool do_bias = HAS_BIAS && (id % tiles_k == 0);
+    constexpr bool do_bias = DO_BIAS;
     f32x16_t bacc;                  // wave (wn, wk) sums the 32 columns of n-block a = wk
 #pragma unroll
     for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
@@ -277,7 +275,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
     };
 
     // one k-step: 8 MFMAs on fragment set S while the next k-step's fragments land in set S^1
-    auto kstep = [&](auto set, auto prefetch, int nslot, int ns) {
+    auto kstep = [&](auto set, auto prefetch, int nslot, int ns, bool bias_now) {
         constexpr int S = decltype(set)::value;
         constexpr bool PREFETCH = decltype(prefetch)::value;
 #pragma unroll
@@ -289,7 +287,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
                 if (a < 2) fb[S ^ 1][a] = frag(nslot, ns, xoff[a]);
             }
         }
-        if (HAS_BIAS) {   // every k-tile does the (cheap) extra MFMA; only k-tile 0 publishes it
+        if (DO_BIAS && bias_now) {   // uniform branch: this workgroup's share of the M stages
             const u32x4_t f0 = __builtin_bit_cast(u32x4_t, fa[S][0]), f1 = __builtin_bit_cast(u32x4_t, fa[S][1]);
             const u32x4_t f2 = __builtin_bit_cast(u32x4_t, fa[S][2]), f3 = __builtin_bit_cast(u32x4_t, fa[S][3]);
             u32x4_t mine;
@@ -305,6 +303,10 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
 #undef VA_GRP
         }
     };
+    // the bias column sums are spread over the k-tile workgroups of an output row: each takes every
+    // tiles_k-th stage, so no workgroup carries more than 1/tiles_k of the extra MFMAs
+    const int my_ktile = id % tiles_k;
+    auto bias_stage = [&](int stage_idx) { return DO_BIAS && (stage_idx % tiles_k) == my_ktile; };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using Yes = std::integral_constant<bool, true>;
@@ -330,22 +332,22 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stage(kt + 4, slot == 0 ? RRING - 1 : slot - 1);
-        kstep(S0{}, Yes{}, slot, 1);
-        kstep(S1{}, Yes{}, advance(slot), 0);
+        kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
+        kstep(S1{}, Yes{}, advance(slot), 0, bias_stage(kt));
         slot = advance(slot);
     }
     // tail: stages nk-4 .. nk-1
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    kstep(S0{}, Yes{}, slot, 1);
-    kstep(S1{}, Yes{}, advance(slot), 0);
+    kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
+    kstep(S1{}, Yes{}, advance(slot), 0, bias_stage(kt));
     slot = advance(slot); ++kt;
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    kstep(S0{}, Yes{}, slot, 1);
-    kstep(S1{}, Yes{}, advance(slot), 0);
+    kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
+    kstep(S1{}, Yes{}, advance(slot), 0, bias_stage(kt));
     slot = advance(slot); ++kt;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -354,11 +356,11 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
         zero_tail(advance(slot), tail_valid);
         __syncthreads();
     }
-    kstep(S0{}, Yes{}, slot, 1);
-    kstep(S1{}, Yes{}, advance(slot), 0);
+    kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
+    kstep(S1{}, Yes{}, advance(slot), 0, bias_stage(kt));
     slot = advance(slot); ++kt;
-    kstep(S0{}, Yes{}, slot, 1);
-    kstep(S1{}, No{}, 0, 0);
+    kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
+    kstep(S1{}, No{}, 0, 0, bias_stage(kt));
 
     const int hh = lane >> 5, col = lane & 31;
 #pragma unroll
@@ -373,6 +375,18 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 16; ++i) unsafeAtomicAdd(DBIAS + n0 + wn * 128 + wk * 32 + acc32_row(i, hh), bacc[i]);
     }
+}
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
+                                                           int M, int N, int K, int lddy, int ldx,
+                                                           float* __restrict__ DW, int lddw, int m_per_slice,
+                                                           float* __restrict__ DBIAS) {
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_k = K / 256;
+    const int tiles = (N / 256) * tiles_k;
+    (void)tiles;
+    gemm_tn_ring_body<HAS_BIAS>(DY, X, M, N, K, lddy, ldx, DW, lddw, m_per_slice, DBIAS, work);
 }
 
 }  // namespace
