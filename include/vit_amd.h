@@ -95,9 +95,10 @@ int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, int64_t Tp, 
 int va_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N, int64_t H,
                 int64_t hd, int64_t ldqkv, int64_t ldo, va_stream_t stream);
 /* backward of the same: given o, do (bf16, layout of o), lse2, writes dq, dk, dv (layout of q/k/v, ld =
- * lddqkv).  delta[b*H+h][n] f32 is workspace of B*H*N floats. */
+ * lddqkv).  workspace: 5*B*H*N floats, 16-byte aligned (per-query softmax statistics in the two forms the
+ * dQ and dK/dV passes consume). */
 int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2,
-                float* delta, void* dq, void* dk, void* dv, int64_t B, int64_t N, int64_t H, int64_t hd,
+                float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N, int64_t H, int64_t hd,
                 int64_t ldqkv, int64_t ldo, int64_t lddqkv, va_stream_t stream);
 
 /* ---- parameter casts -------------------------------------------------------------------------------

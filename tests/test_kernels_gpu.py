@@ -40,7 +40,7 @@ def rel_err(a, b):
 @pytest.mark.parametrize("M,N,K,tile", [(8, 1024, 1024, 128), (300, 3072, 1024, 128), (1000, 1024, 1536, 128),
                                         (2048, 4096, 1024, 256), (2048 + 17, 1024, 4096, 256), (513, 3072, 1024, 256),
                                         (300, 256, 128, 256), (2048, 1024, 1536, 256), (2048, 4096, 1024, 1256), (2048, 3072, 1024, 2256), (700, 1024, 128, 256), (700, 1024, 192, 256),
-                                        (4096, 1024, 1024, 0)])
+                                        (4096, 1024, 1024, 0), (10240, 3072, 256, 256), (256 * 37, 1792, 128, 256)])
 def test_gemm_nt_plain(ops, dev, M, N, K, tile):
     x = rnd((M, K), dev, 1, dtype=BF16)
     w = rnd((N, K), dev, 2, 1.0 / math.sqrt(K), dtype=BF16)
@@ -65,9 +65,9 @@ def test_gemm_nt_layout_is_not_transposed(ops, dev):
     assert torch.equal(out.float(), (x.float() @ w.float().t()))
 
 
-@pytest.mark.parametrize("tile", [128, 256, 1256, 2256])
-def test_gemm_nt_epilogues(ops, dev, tile):
-    M, N, K = 700, 1024, 1024
+@pytest.mark.parametrize("tile,M", [(128, 700), (256, 700), (1256, 700), (2256, 700), (256, 256 * 9)])
+def test_gemm_nt_epilogues(ops, dev, tile, M):
+    N, K = 1024, 1024
     x = rnd((M, K), dev, 3, dtype=BF16)
     w = rnd((N, K), dev, 4, 1.0 / math.sqrt(K), dtype=BF16)
     bias = rnd((N,), dev, 5, 0.5)

@@ -16,6 +16,7 @@
 //     index XOR f(row), f chosen so both patterns hit all 64 banks (see swz()).
 //   * dQ and dK/dV are separate passes (scores recomputed in each): no atomics, bitwise reproducible.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -27,12 +28,12 @@ VA_DEVINL int swz(int row) {
     return ((row & 3) << 2) | ((row >> 2) & 3);                          // 16 chunks per 256-byte row
 }
 
-// Stage a [64 x HD] bf16 tile: rows row0..row0+63 (clamped to n_rows-1) of `src` (row stride ld).
-template <int HD>
-VA_DEVINL void stage_tile(const bf16_t* __restrict__ src, int64_t ld, int row0, int n_rows, char* dst, int tid,
+// Stage a [ROWS x HD] bf16 tile: rows row0..row0+ROWS-1 (clamped to n_rows-1) of `src` (row stride ld).
+template <int HD, int ROWS = TILE_ROWS>
+VA_DEVINL void stage_tile(const bf16_t* src, int64_t ld, int row0, int n_rows, char* dst, int tid,
                           int wave) {
     constexpr int CPR = HD / 8;                 // chunks per row
-    constexpr int PER_THREAD = TILE_ROWS * CPR / 256;
+    constexpr int PER_THREAD = ROWS * CPR / 256;
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
         const int q = i * 256 + tid;
@@ -44,10 +45,36 @@ VA_DEVINL void stage_tile(const bf16_t* __restrict__ src, int64_t ld, int row0, 
     }
 }
 
+// Per-thread byte offsets of its chunks inside a 64-row tile, computed once; whole tiles are then staged
+// from a wave-uniform tile base plus these 32-bit offsets (no per-tile address arithmetic on the VALU).
+template <int HD>
+struct TileSrc {
+    static constexpr int CPR = HD / 8, PER_THREAD = TILE_ROWS * CPR / 256;
+    uint32_t off[PER_THREAD];
+    VA_DEVINL void init(int64_t ld, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int q = i * 256 + tid, row = q / CPR;
+            off[i] = (uint32_t)(row * ld * 2) + (((q % CPR) ^ swz<HD>(row)) << 4);
+        }
+    }
+};
+template <int HD, bool RAGGED>
+VA_DEVINL void stage_tile_at(const TileSrc<HD>& ts, const bf16_t* src, int64_t ld, int row0, int n_rows,
+                             char* dst, int tid, int wave) {
+    if (RAGGED && row0 + TILE_ROWS > n_rows) {
+        stage_tile<HD>(src, ld, row0, n_rows, dst, tid, wave);
+        return;
+    }
+    const char* base = (const char*)(src + (int64_t)row0 * ld);
+#pragma unroll
+    for (int i = 0; i < TileSrc<HD>::PER_THREAD; ++i) glds16(base + ts.off[i], dst + (i * 256 + wave * 64) * 16);
+}
+
 // Row-read fragment (MFMA operand with the tile's rows as the M/N index): lane (r = lane&31, h = lane>>5)
 // gets tile[row_base + r][16*ks + 8h .. +7].
 template <int HD>
-VA_DEVINL bf16x8_t row_frag(const char* tile, int row_base, int ks, int lane) {
+VA_DEVINL bf16x8_t row_frag(const char* __restrict__ tile, int row_base, int ks, int lane) {
     const int row = row_base + (lane & 31);
     const int chunk = (2 * ks + (lane >> 5)) ^ swz<HD>(row);
     return *(const bf16x8_t*)(tile + row * (HD * 2) + (chunk << 4));
@@ -57,7 +84,7 @@ VA_DEVINL bf16x8_t row_frag(const char* tile, int row_base, int ks, int lane) {
 // k' = row_base + {0..15} for the 32 columns cb*32 .. cb*32+31, in the k-order of an accumulator tile used
 // as the B operand: element j of lane half h is row  row_base + 8*(j>>2) + 4h + (j&3).
 template <int HD>
-VA_DEVINL bf16x8_t tr_frag(const char* tile, int row_base, int cb, int lane) {
+VA_DEVINL bf16x8_t tr_frag(const char* __restrict__ tile, int row_base, int cb, int lane) {
     const int gi = lane >> 4, cg = gi & 1, h = gi >> 1, q = (lane & 15) >> 2, p = lane & 3;
     const int r0 = row_base + 4 * h + q, r1 = r0 + 8;
     const int chunk = 4 * cb + 2 * cg + (p >> 1);
@@ -73,7 +100,27 @@ VA_DEVINL bf16x8_t pack_acc(const f32x16_t& x, int s) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// A bf16 fragment times a scalar, rounded back to bf16.
+VA_DEVINL bf16x8_t scale_frag(bf16x8_t raw, float c) {
+    u32x4_t pk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pk[j] = pack_bf16x2((float)raw[2 * j] * c, (float)raw[2 * j + 1] * c);
+    return __builtin_bit_cast(bf16x8_t, pk);
+}
+
+// max of three without the NaN-quieting moves fmaxf adds in front of every MFMA result
+VA_DEVINL float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 VA_DEVINL float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+// Same through the half-wave swap instruction (no LDS round trip, no NaN quieting).
+VA_DEVINL float xhalf_max_fast(float v) {
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return max3(__uint_as_float(r[0]), __uint_as_float(r[1]), v);
+}
 VA_DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Store a transposed 32-wide accumulator set acc[cb][i] = T[col = cb*32 + acc32_row(i,h)][row = lane&31]
@@ -90,8 +137,18 @@ VA_DEVINL void store_rows(const f32x16_t (&acc)[HD / 32], float mul, bf16_t* out
         }
 }
 
+// LDS ring depth of the forward kernel: three 16 KiB slots at head dim 64 (three workgroups per CU still
+// fit), two 32 KiB slots at head dim 128.
+constexpr int fwd_ring_slots(int hd) { return hd == 64 ? 3 : 2; }
+
 // ------------------------------------------------------------------------------------------------
-// forward
+// forward.  The loop is bound by vector-instruction issue (32 exponentials + the bookkeeping per lane and
+// 64-key tile against 16 MFMAs), so the bookkeeping is kept off the VALU:
+//  * Q is scaled by log2(e)/sqrt(hd) once, and the score accumulators START at -m (a register block that
+//    only changes when the maximum moves), so the MFMA chain itself delivers s*c - m: no per-score fma;
+//  * the running maximum m is only raised when some row's tile maximum exceeds it by more than 2^THR
+//    (probabilities then stay below 2^THR, harmless in bf16 x f32), so rescaling O is a rare,
+//    wave-uniform branch taken before any score of the tile is exponentiated.
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
@@ -99,7 +156,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                                                        float* __restrict__ LSE2, int N, int H, int64_t ld, int64_t ldo,
                                                        float c) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+    constexpr int NBUF = fwd_ring_slots(HD), AHEAD = NBUF - 1, LOADS = 2 * TileSrc<HD>::PER_THREAD;
+    constexpr float THR = 6.0f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
@@ -112,37 +171,79 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int qrow_c = qrow < N ? qrow : N - 1;
     bf16x8_t qf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(Qb + (int64_t)qrow_c * ld + ks * 16 + h * 8);
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t raw = *(const bf16x8_t*)(Qb + (int64_t)qrow_c * ld + ks * 16 + h * 8);
+        u32x4_t pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            pk[j] = pack_bf16x2((float)raw[2 * j] * c, (float)raw[2 * j + 1] * c);
+        qf[ks] = __builtin_bit_cast(bf16x8_t, pk);
+    }
 
-    f32x16_t o[CB];
+    f32x16_t o[CB], negm;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[cb][i] = 0.f;
-    float m = -INFINITY, l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+    float m = 0.f, l = 0.f;
 
     const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
-    stage_tile<HD>(Kb, ld, 0, N, smem, tid, wave);
-    stage_tile<HD>(Vb, ld, 0, N, smem + TB, tid, wave);
-    for (int t = 0; t < nt; ++t) {
-        wait_vm0();
-        __syncthreads();
-        if (t + 1 < nt) {
-            char* nb = smem + ((t + 1) & 1) * 2 * TB;
-            stage_tile<HD>(Kb, ld, (t + 1) * TILE_ROWS, N, nb, tid, wave);
-            stage_tile<HD>(Vb, ld, (t + 1) * TILE_ROWS, N, nb + TB, tid, wave);
-        }
-        const char* kt = smem + (t & 1) * 2 * TB;
+    TileSrc<HD> ts;
+    ts.init(ld, tid);
+    auto stage = [&](int tile, int slot) {
+        char* nb = smem + slot * 2 * TB;
+        stage_tile_at<HD, RAGGED>(ts, Kb, ld, tile * TILE_ROWS, N, nb, tid, wave);
+        stage_tile_at<HD, RAGGED>(ts, Vb, ld, tile * TILE_ROWS, N, nb + TB, tid, wave);
+    };
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (i < nt) stage(i, i);
+    // One tile.  SLOT is a compile-time constant (the tile loop is unrolled by the ring depth), so every LDS
+    // address is a loop-invariant register plus an immediate.  Tile t+AHEAD is issued in the middle of the
+    // step, once all of this tile's LDS reads are on their way.
+#ifdef VA_ATTN_PROFILE
+    uint64_t pc[4] = {0, 0, 0, 0};
+#define VA_STAMP(i) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); pc[i] += now_ - last_; last_ = now_; }
+#else
+#define VA_STAMP(i)
+#endif
+    auto tile_step = [&](int t, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+#ifdef VA_ATTN_PROFILE
+        uint64_t last_ = __builtin_amdgcn_s_memtime();
+#endif
+        if (AHEAD > 1 && t + AHEAD - 1 < nt) wait_vm<LOADS*(AHEAD - 1)>();
+        else wait_vm0();
+        // raw barrier: __syncthreads() carries a fence that drains vmcnt to zero
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        VA_STAMP(0)
+        const char* kt = smem + SLOT * 2 * TB;
         const char* vt = kt + TB;
 
-        f32x16_t st[2];
+        bf16x8_t kf[2][KS];   // every LDS read of a phase is issued before its first MFMA
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = row_frag<HD>(kt, kb * 32, ks, lane);
+        f32x16_t st[2];   // scores of this tile relative to the running maximum, log2 units
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            st[kb] = mfma32(kf[kb][0], qf[0], negm);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) st[kb] = mfma32(row_frag<HD>(kt, kb * 32, ks, lane), qf[ks], st[kb]);
+            for (int ks = 1; ks < KS; ++ks) st[kb] = mfma32(kf[kb][ks], qf[ks], st[kb]);
         }
+        bf16x8_t vf[2][2][CB];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) vf[kb][s][cb] = tr_frag<HD>(vt, kb * 32 + 16 * s, cb, lane);
+        if (t + AHEAD < nt) stage(t + AHEAD, (SLOT + AHEAD) % NBUF);
         if (RAGGED && t == nt - 1) {   // RAGGED <=> N % 64 != 0: only that build carries the selects
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -150,25 +251,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 for (int i = 0; i < 16; ++i)
                     if (t * TILE_ROWS + kb * 32 + acc32_row(i, h) >= N) st[kb][i] = -INFINITY;
         }
-        float mx = st[0][0];
+        float mq[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int g = 0; g < 4; ++g) {
+            mq[g] = max3(st[0][4 * g], st[0][4 * g + 1], st[0][4 * g + 2]);
+            mq[g] = max3(mq[g], st[0][4 * g + 3], st[1][4 * g]);
+            mq[g] = max3(mq[g], st[1][4 * g + 1], st[1][4 * g + 2]);
+        }
+        float mx = max3(max3(mq[0], st[1][3], st[1][7]), max3(mq[1], st[1][11], st[1][15]), max3(mq[2], mq[3], mq[2]));
+        mx = xhalf_max_fast(mx);
+        VA_STAMP(1)
+        if (t == 0 || !__all(mx <= THR)) {
+            // move the maximum: by the tile's own maximum on the first tile (either sign), upwards only later
+            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = t == 0 ? 1.f : fast_exp2(-delta);
+            m += delta;
+            l *= alpha;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[kb][i]);
-        mx = xhalf_max(mx);
-        const float m_new = fmaxf(m, mx * c);
-        const float alpha = fast_exp2(m - m_new);
-        m = m_new;
-        l *= alpha;
+            for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+                for (int i = 0; i < 16; ++i) o[cb][i] *= alpha;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[cb][i] *= alpha;
+            for (int i = 0; i < 16; ++i) {
+                negm[i] = -m;
+                st[0][i] -= delta;
+                st[1][i] -= delta;
+            }
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = fast_exp2(fmaf(st[kb][i], c, -m_new));
+                const float p = fast_exp2(st[kb][i]);
                 st[kb][i] = p;
                 l += p;
             }
@@ -178,22 +292,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             for (int s = 0; s < 2; ++s) {
                 const bf16x8_t pf = pack_acc(st[kb], s);
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) o[cb] = mfma32(tr_frag<HD>(vt, kb * 32 + 16 * s, cb, lane), pf, o[cb]);
+                for (int cb = 0; cb < CB; ++cb) o[cb] = mfma32(vf[kb][s][cb], pf, o[cb]);
             }
+        VA_STAMP(2)
+    };
+    for (int t0 = 0; t0 < nt; t0 += NBUF) {
+        tile_step(t0, std::integral_constant<int, 0>{});
+        if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
+        if (NBUF > 2 && t0 + 2 < nt) tile_step(t0 + 2, std::integral_constant<int, (NBUF > 2 ? 2 : 0)>{});
     }
     l += __shfl_xor(l, 32);
     if (qrow < N) {
         store_rows<HD>(o, 1.0f / l, O + ((int64_t)b * N + qrow) * ldo + hh * HD, h);
         if (h == 0) LSE2[(int64_t)bh * N + qrow] = m + __log2f(l);
     }
+#ifdef VA_ATTN_PROFILE
+    if (lane < 3) LSE2[(int64_t)bh * N + q0 + lane] = (float)pc[lane] / nt;
+#endif
+#undef VA_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
 // delta[bh][n] = sum_d dO * O      (one 8-lane group per (token, head) for HD=64, 16 lanes for 128)
+// Also writes, per (bh, n), the 16-byte record the dK/dV pass feeds to the matrix pipe: -lse2 and -delta,
+// each split exactly into three bf16 terms {hi, mid | lo, 0} (8+8+8 mantissa bits), laid out as the first
+// two dwords of an MFMA operand fragment.
 // ------------------------------------------------------------------------------------------------
+VA_DEVINL void split3_bf16(float x, uint32_t& d0, uint32_t& d1) {
+    const uint32_t hi = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(hi);
+    const uint32_t mid = __float_as_uint(r) & 0xffff0000u;
+    const float lo = r - __uint_as_float(mid);
+    d0 = (hi >> 16) | mid;
+    d1 = __float_as_uint(lo) >> 16;    // at most 8 significant bits are left: exact
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ DO,
-                                                         float* __restrict__ delta, int64_t rows, int N, int H,
+                                                         const float* __restrict__ LSE2, float* __restrict__ delta,
+                                                         u32x4_t* __restrict__ aux, int64_t rows, int N, int H,
                                                          int64_t ldo) {
     constexpr int LPH = HD / 8;   // lanes per (row, head)
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -216,7 +353,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     for (int off = LPH / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (live && part == 0) {
         const int64_t b = row / N, n = row % N;
-        delta[(b * H + hh) * N + n] = s;
+        const int64_t at = (b * H + hh) * N + n;
+        delta[at] = s;
+        u32x4_t rec;
+        uint32_t d0, d1;
+        split3_bf16(-LSE2[at], d0, d1);
+        rec[0] = d0; rec[1] = d1;
+        split3_bf16(-s, d0, d1);
+        rec[2] = d0; rec[3] = d1;
+        aux[at] = rec;
     }
 }
 
@@ -243,14 +388,19 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
 
     const int qrow = q0 + (lane & 31);
     const int qrow_c = qrow < N ? qrow : N - 1;
-    bf16x8_t qf[KS], dof[KS];
+    bf16x8_t qf[KS], dof[KS];   // qf carries the softmax scale (as in the forward kernel)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = *(const bf16x8_t*)(Qb + (int64_t)qrow_c * ld + ks * 16 + h * 8);
+        qf[ks] = scale_frag(*(const bf16x8_t*)(Qb + (int64_t)qrow_c * ld + ks * 16 + h * 8), c);
         dof[ks] = *(const bf16x8_t*)(DOb + (int64_t)qrow_c * ldo + ks * 16 + h * 8);
     }
+    // A lane holds one query's column of every score tile, so -lse and -delta are per-lane constants: the
+    // score / dP accumulators start from them and the MFMA chains deliver s*c - lse and dP - delta directly.
     const float lse = LSE2[(int64_t)bh * N + qrow_c];
     const float dl = DELTA[(int64_t)bh * N + qrow_c];
+    f32x16_t neg_lse, neg_dl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { neg_lse[i] = -lse; neg_dl[i] = -dl; }
 
     f32x16_t dq[CB];
 #pragma unroll
@@ -259,60 +409,84 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
         for (int i = 0; i < 16; ++i) dq[cb][i] = 0.f;
 
     const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
-    stage_tile<HD>(Kb, ld, 0, N, smem, tid, wave);
-    stage_tile<HD>(Vb, ld, 0, N, smem + TB, tid, wave);
-    for (int t = 0; t < nt; ++t) {
+    TileSrc<HD> ts;
+    ts.init(ld, tid);
+    auto stage = [&](int tile, int slot) {
+        char* nb = smem + slot * 2 * TB;
+        stage_tile_at<HD, RAGGED>(ts, Kb, ld, tile * TILE_ROWS, N, nb, tid, wave);
+        stage_tile_at<HD, RAGGED>(ts, Vb, ld, tile * TILE_ROWS, N, nb + TB, tid, wave);
+    };
+    stage(0, 0);
+    auto tile_step = [&](int t, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
         wait_vm0();
-        __syncthreads();
-        if (t + 1 < nt) {
-            char* nb = smem + ((t + 1) & 1) * 2 * TB;
-            stage_tile<HD>(Kb, ld, (t + 1) * TILE_ROWS, N, nb, tid, wave);
-            stage_tile<HD>(Vb, ld, (t + 1) * TILE_ROWS, N, nb + TB, tid, wave);
-        }
-        const char* kt = smem + (t & 1) * 2 * TB;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < nt) stage(t + 1, SLOT ^ 1);
+        const char* kt = smem + SLOT * 2 * TB;
         const char* vt = kt + TB;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16_t s, dp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            bf16x8_t kfr[KS], vfr[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s = mfma32(row_frag<HD>(kt, kb * 32, ks, lane), qf[ks], s);
-                dp = mfma32(row_frag<HD>(vt, kb * 32, ks, lane), dof[ks], dp);
+                kfr[ks] = row_frag<HD>(kt, kb * 32, ks, lane);
+                vfr[ks] = row_frag<HD>(vt, kb * 32, ks, lane);
             }
+            f32x16_t s = mfma32(kfr[0], qf[0], neg_lse);
+            f32x16_t dp = mfma32(vfr[0], dof[0], neg_dl);
+#pragma unroll
+            for (int ks = 1; ks < KS; ++ks) {
+                s = mfma32(kfr[ks], qf[ks], s);
+                dp = mfma32(vfr[ks], dof[ks], dp);
+            }
+            bf16x8_t ktr[2][CB];
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) ktr[sidx][cb] = tr_frag<HD>(kt, kb * 32 + 16 * sidx, cb, lane);
             const bool ragged = RAGGED && (t == nt - 1);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float p = fast_exp2(fmaf(s[i], c, -lse));
+                float p = fast_exp2(s[i]);
                 if (ragged && t * TILE_ROWS + kb * 32 + acc32_row(i, h) >= N) p = 0.f;
-                s[i] = p * (dp[i] - dl);
+                s[i] = p * dp[i];
             }
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
                 const bf16x8_t dsf = pack_acc(s, sidx);
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-                    dq[cb] = mfma32(tr_frag<HD>(kt, kb * 32 + 16 * sidx, cb, lane), dsf, dq[cb]);
+                for (int cb = 0; cb < CB; ++cb) dq[cb] = mfma32(ktr[sidx][cb], dsf, dq[cb]);
             }
         }
+    };
+    for (int t0 = 0; t0 < nt; t0 += 2) {
+        tile_step(t0, std::integral_constant<int, 0>{});
+        if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
     }
     if (qrow < N) store_rows<HD>(dq, scale, DQ + ((int64_t)b * N + qrow) * lddq + hh * HD, h);
 }
 
 // ------------------------------------------------------------------------------------------------
-// dK/dV pass: key-stationary, streams Q and dO (plus the per-query lse2 and delta).
+// dK/dV pass: key-stationary, streams Q and dO.  Here a lane holds one KEY's column of the score tile and
+// the queries run over the accumulator registers, so -lse2 / -delta differ per register.  They enter
+// through the matrix pipe instead of the VALU: one extra 16-deep MFMA slice per chain whose A operand
+// carries the three bf16 terms of -lse2[query] (or -delta[query]) in k = 0..2 and whose B operand is 1.0
+// there; the chains then deliver s*c - lse2 and dP - delta directly.  K carries the softmax scale.
 // ------------------------------------------------------------------------------------------------
+template <int HD>
+constexpr int dkv_stage_bytes() { return 2 * TILE_ROWS * HD * 2 + TILE_ROWS * 16; }   // Q | dO | records
+
 template <int HD, bool RAGGED>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
-                                                           const float* __restrict__ LSE2,
-                                                           const float* __restrict__ DELTA, bf16_t* __restrict__ DK,
+                                                           const u32x4_t* __restrict__ AUX, bf16_t* __restrict__ DK,
                                                            bf16_t* __restrict__ DV, int N, int H, int64_t ld,
                                                            int64_t ldo, int64_t lddq, float c, float scale) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
-    constexpr int STAGE = 2 * TB + 2 * TILE_ROWS * 4;   // Q tile | dO tile | lse2[64] | delta[64]
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = dkv_stage_bytes<HD>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE] | 16 zero bytes
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, hh = bh % H;
@@ -321,74 +495,88 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
     const bf16_t* Kb = K + (int64_t)b * N * ld + hh * HD;
     const bf16_t* Vb = V + (int64_t)b * N * ld + hh * HD;
     const bf16_t* DOb = DO + (int64_t)b * N * ldo + hh * HD;
-    const float* lse_b = LSE2 + (int64_t)bh * N;
-    const float* dl_b = DELTA + (int64_t)bh * N;
+    const u32x4_t* aux_b = AUX + (int64_t)bh * N;
 
     const int krow = k0 + (lane & 31);
     const int krow_c = krow < N ? krow : N - 1;
     bf16x8_t kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = *(const bf16x8_t*)(Kb + (int64_t)krow_c * ld + ks * 16 + h * 8);
+        kf[ks] = scale_frag(*(const bf16x8_t*)(Kb + (int64_t)krow_c * ld + ks * 16 + h * 8), c);
         vf[ks] = *(const bf16x8_t*)(Vb + (int64_t)krow_c * ld + ks * 16 + h * 8);
     }
+    // B operand of the extra slice: 1.0 at k = 0..2 (lane half 0 holds k = 0..7), zero elsewhere
+    const u32x4_t ones_u = {h == 0 ? 0x3f803f80u : 0u, h == 0 ? 0x00003f80u : 0u, 0u, 0u};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
+    if (tid < 4) ((uint32_t*)(smem + 2 * STAGE))[tid] = 0u;   // what lane half 1 reads as its (all-zero) record
+
     f32x16_t dk[CB], dv[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[cb][i] = 0.f; dv[cb][i] = 0.f; }
 
-    // per-query scalars of a tile, also by direct-to-LDS loads (4 bytes per lane): wave 0 brings lse2[64],
-    // wave 1 delta[64]; rows past N are clamped here and masked in the compute.
-    auto stage_scalars = [&](int t, char* stg) {
-        if (wave < 2) {
-            int r = t * TILE_ROWS + lane;
+    const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
+    TileSrc<HD> ts_q, ts_do;
+    ts_q.init(ld, tid);
+    ts_do.init(ldo, tid);
+    auto stage = [&](int tile, int slot) {
+        char* nb = smem + slot * STAGE;
+        stage_tile_at<HD, RAGGED>(ts_q, Qb, ld, tile * TILE_ROWS, N, nb, tid, wave);
+        stage_tile_at<HD, RAGGED>(ts_do, DOb, ldo, tile * TILE_ROWS, N, nb + TB, tid, wave);
+        if (wave == 0) {   // 64 records of 16 bytes; rows past N are clamped here and masked in the compute
+            int r = tile * TILE_ROWS + lane;
             r = r < N ? r : N - 1;
-            const float* src = (wave == 0 ? lse_b : dl_b) + r;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(stg + 2 * TB + wave * 256), 4, 0, 0);
+            glds16(aux_b + r, nb + 2 * TB);
         }
     };
-
-    const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
-    stage_tile<HD>(Qb, ld, 0, N, smem, tid, wave);
-    stage_tile<HD>(DOb, ldo, 0, N, smem + TB, tid, wave);
-    stage_scalars(0, smem);
-    for (int t = 0; t < nt; ++t) {
+    stage(0, 0);
+    auto tile_step = [&](int t, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
         wait_vm0();
-        __syncthreads();
-        if (t + 1 < nt) {
-            char* nb = smem + ((t + 1) & 1) * STAGE;
-            stage_tile<HD>(Qb, ld, (t + 1) * TILE_ROWS, N, nb, tid, wave);
-            stage_tile<HD>(DOb, ldo, (t + 1) * TILE_ROWS, N, nb + TB, tid, wave);
-            stage_scalars(t + 1, nb);
-        }
-        const char* qt = smem + (t & 1) * STAGE;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < nt) stage(t + 1, SLOT ^ 1);
+        const char* qt = smem + SLOT * STAGE;
         const char* dot = qt + TB;
-        const float* lse_t = (const float*)(qt + 2 * TB);
-        const float* dl_t = lse_t + TILE_ROWS;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            const char* rec_at = h == 0 ? qt + 2 * TB + (qb * 32 + (lane & 31)) * 16 : smem + 2 * STAGE;
+            const u32x4_t rec = *(const u32x4_t*)rec_at;
+            const u32x4_t a_lse = {rec[0], rec[1], 0u, 0u}, a_dl = {rec[2], rec[3], 0u, 0u};
+            bf16x8_t qfr[KS], dofr[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qfr[ks] = row_frag<HD>(qt, qb * 32, ks, lane);
+                dofr[ks] = row_frag<HD>(dot, qb * 32, ks, lane);
+            }
             f32x16_t s, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+            s = mfma32(__builtin_bit_cast(bf16x8_t, a_lse), ones, s);       // [query][key] = -lse2[query]
+            dp = mfma32(__builtin_bit_cast(bf16x8_t, a_dl), ones, dp);      //               -delta[query]
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s = mfma32(row_frag<HD>(qt, qb * 32, ks, lane), kf[ks], s);      // [query][key]
-                dp = mfma32(row_frag<HD>(dot, qb * 32, ks, lane), vf[ks], dp);
+                s = mfma32(qfr[ks], kf[ks], s);
+                dp = mfma32(dofr[ks], vf[ks], dp);
             }
+            bf16x8_t dotr[2][CB], qtr[2][CB];
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    dotr[sidx][cb] = tr_frag<HD>(dot, qb * 32 + 16 * sidx, cb, lane);
+                    qtr[sidx][cb] = tr_frag<HD>(qt, qb * 32 + 16 * sidx, cb, lane);
+                }
             f32x16_t pr;
             const bool ragged = RAGGED && (t == nt - 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4_t lv = *(const f32x4_t*)(lse_t + qb * 32 + 8 * g + 4 * h);
-                const f32x4_t dv4 = *(const f32x4_t*)(dl_t + qb * 32 + 8 * g + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float p = fast_exp2(fmaf(s[4 * g + j], c, -lv[j]));
-                    if (ragged && t * TILE_ROWS + qb * 32 + 8 * g + 4 * h + j >= N) p = 0.f;
-                    pr[4 * g + j] = p;
-                    s[4 * g + j] = p * (dp[4 * g + j] - dv4[j]);
-                }
+            for (int i = 0; i < 16; ++i) {
+                float p = fast_exp2(s[i]);
+                if (ragged && t * TILE_ROWS + qb * 32 + acc32_row(i, h) >= N) p = 0.f;
+                pr[i] = p;
+                s[i] = p * dp[i];
             }
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
@@ -396,11 +584,15 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
                 const bf16x8_t dsf = pack_acc(s, sidx);
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
-                    dv[cb] = mfma32(tr_frag<HD>(dot, qb * 32 + 16 * sidx, cb, lane), pf, dv[cb]);
-                    dk[cb] = mfma32(tr_frag<HD>(qt, qb * 32 + 16 * sidx, cb, lane), dsf, dk[cb]);
+                    dv[cb] = mfma32(dotr[sidx][cb], pf, dv[cb]);
+                    dk[cb] = mfma32(qtr[sidx][cb], dsf, dk[cb]);
                 }
             }
         }
+    };
+    for (int t0 = 0; t0 < nt; t0 += 2) {
+        tile_step(t0, std::integral_constant<int, 0>{});
+        if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
     }
     if (krow < N) {
         store_rows<HD>(dk, scale, DK + ((int64_t)b * N + krow) * lddq + hh * HD, h);
@@ -434,7 +626,7 @@ int check_common(const char* who, int64_t B, int64_t N, int64_t H, int64_t hd, i
 template <int HD>
 int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
                int64_t ld, int64_t ldo, hipStream_t stream) {
-    constexpr int LDS = 2 * 2 * TILE_ROWS * HD * 2;
+    constexpr int LDS = fwd_ring_slots(HD) * 2 * TILE_ROWS * HD * 2;
     static bool flags[2][64] = {};
     const float c = 1.4426950408889634f / sqrtf((float)HD);
     const dim3 grid((N + 127) / 128, B * H);
@@ -451,10 +643,10 @@ int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, flo
 
 template <int HD>
 int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* d_o,
-               const float* lse2, float* delta, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H, int64_t ld,
+               const float* lse2, float* workspace, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H, int64_t ld,
                int64_t ldo, int64_t lddq, hipStream_t stream) {
     constexpr int LDS_DQ = 2 * 2 * TILE_ROWS * HD * 2;
-    constexpr int LDS_DKV = 2 * (2 * TILE_ROWS * HD * 2 + 2 * TILE_ROWS * 4);
+    constexpr int LDS_DKV = 2 * dkv_stage_bytes<HD>() + 16;
     static bool f1[2][64] = {}, f2[2][64] = {};
     const bool ragged = (N % TILE_ROWS) != 0;
     if (ragged) {
@@ -468,8 +660,11 @@ int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* 
     const float c = 1.4426950408889634f * scale;
     const int64_t rows = (int64_t)B * N;
     const int64_t threads = rows * H * (HD / 8);
+    // workspace: [B*H*N] 16-byte records for the dK/dV pass, then [B*H*N] f32 delta for the dQ pass
+    u32x4_t* aux = (u32x4_t*)workspace;
+    float* delta = workspace + 4 * rows * H;
     hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, o, d_o,
-                       delta, rows, N, H, ldo);
+                       lse2, delta, aux, rows, N, H, ldo);
     VA_CHECK_LAUNCH("va_attn_bwd(delta)");
     const dim3 grid((N + 127) / 128, B * H);
     if (ragged)
@@ -480,10 +675,10 @@ int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* 
                            N, H, ld, ldo, lddq, c, scale);
     VA_CHECK_LAUNCH("va_attn_bwd(dq)");
     if (ragged)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, lse2, delta,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux,
                            dk, dv, N, H, ld, ldo, lddq, c, scale);
     else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, lse2, delta,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux,
                            dk, dv, N, H, ld, ldo, lddq, c, scale);
     VA_CHECK_LAUNCH("va_attn_bwd(dkv)");
     return VA_OK;
@@ -504,9 +699,10 @@ extern "C" int va_attn_fwd(const void* q, const void* k, const void* v, void* o,
 }
 
 extern "C" int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                           const float* lse2, float* delta, void* dq, void* dk, void* dv, int64_t B, int64_t N,
+                           const float* lse2, float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N,
                            int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t lddqkv, hipStream_t stream) {
-    VA_CHECK_ARG(q && k && v && o && d_o && lse2 && delta && dq && dk && dv, "va_attn_bwd: null operand");
+    VA_CHECK_ARG(q && k && v && o && d_o && lse2 && workspace && dq && dk && dv, "va_attn_bwd: null operand");
+    VA_CHECK_ARG((uintptr_t)workspace % 16 == 0, "va_attn_bwd: workspace must be 16-byte aligned");
     if (int e = check_common("va_attn_bwd", B, N, H, hd, ldqkv, ldo)) return e;
     VA_CHECK_ARG(lddqkv >= H * hd && lddqkv % 8 == 0, "va_attn_bwd: bad gradient leading dimension");
     VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq |
@@ -514,9 +710,9 @@ extern "C" int va_attn_bwd(const void* q, const void* k, const void* v, const vo
                  "va_attn_bwd: misaligned operand");
     if (hd == 64)
         return bwd_launch<64>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
-                              lse2, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo,
+                              lse2, workspace, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo,
                               lddqkv, stream);
     return bwd_launch<128>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
-                           lse2, delta, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo, lddqkv,
+                           lse2, workspace, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo, lddqkv,
                            stream);
 }

@@ -63,6 +63,8 @@ VA_DEVINL f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
 }
 
 VA_DEVINL void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+VA_DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Row of accumulator register i in lane-half h for a 32x32 MFMA result.
 VA_DEVINL int acc32_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }

@@ -82,26 +82,41 @@ VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M
     }
 }
 
-// Epilogue for the column-permuted layout of the ring kernel: the weight rows are staged so that MFMA
-// row r of 16-row block a is output column (r>>2)*16 + a*4 + (r&3) of the wave's 64 columns.  A lane then
-// owns 16 CONSECUTIVE output columns of one output row (32 B of bf16 / 64 B of f32), and the four lane
-// groups of a wave write one full 128-byte line of bf16 per output row.
-template <int EPI, int TM>
+// Which weight row (= output column, relative to the wave's 64-column block base `row & ~63`) LDS row `row`
+// of the W image holds in the 256-wide kernels.  MFMA row r of 16-row block a lands in lane group r>>2,
+// register r&3; the order is chosen so that ONE store instruction of the epilogue covers 64 contiguous
+// bytes of every output row (whole 32-byte sectors): for 2-byte outputs lane group g must own columns
+// 8g..8g+7 of each 32-column half, for 4-byte outputs the natural order already does that.
+template <int EPI>
+VA_DEVINL int wide_wrow(int row) {
+    const int r = row & 15, a = (row >> 4) & 3;
+    if (EPI == VA_EPI_F32) return row;
+    return (row & ~63) + (a >> 1) * 32 + (r >> 2) * 8 + (a & 1) * 4 + (r & 3);
+}
+
+// Epilogue for the column-permuted layout of the 256-wide kernels (weight rows staged per wide_wrow): each
+// 16-byte store of a lane group sits next to its neighbours', so a store instruction writes 64 contiguous
+// bytes per output row.
+// FULL_M: all of the wave's rows exist, so the row loop carries no branches (a skipped row block would make
+// the compiler drain the memory counter in front of every later block's stores).
+template <int EPI, int TM, bool FULL_M = false>
 VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
     const int ldc = ep.ldc;
-    const int nb = n_wave + (lane >> 4) * 16;
+    const int g = lane >> 4;
+    // v[4a+j] = acc[a][b][j] is output column  col(a) + j  (see wide_wrow)
+    auto col = [&](int a) { return EPI == VA_EPI_F32 ? n_wave + a * 16 + 4 * g : n_wave + (a >> 1) * 32 + g * 8 + (a & 1) * 4; };
     float bias[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) bias[j] = 0.f;
     if (EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *(f32x4_t*)(bias + 4 * g) = *(const f32x4_t*)(ep.bias + nb + 4 * g);
+        for (int a = 0; a < 4; ++a) *(f32x4_t*)(bias + 4 * a) = *(const f32x4_t*)(ep.bias + col(a));
     }
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
         const int m = m_wave + b * 16 + (lane & 15);
-        if (m >= M) continue;
-        const size_t o = (size_t)m * ldc + nb;
+        if (!FULL_M && m >= M) continue;
+        const size_t o_lo = (size_t)m * ldc + col(0), o_hi = (size_t)m * ldc + col(2);   // 2-byte outputs: 8 + 8 columns
         float v[16];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -110,35 +125,35 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
         if (EPI == VA_EPI_BF16) {
             u32x4_t lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             u32x4_t hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
-            *(u32x4_t*)((bf16_t*)ep.out + o) = lo;
-            *(u32x4_t*)((bf16_t*)ep.out + o + 8) = hi;
+            *(u32x4_t*)((bf16_t*)ep.out + o_lo) = lo;
+            *(u32x4_t*)((bf16_t*)ep.out + o_hi) = hi;
         } else if (EPI == VA_EPI_BIAS_GELU) {
             u32x4_t lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             u32x4_t hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
-            *(u32x4_t*)((bf16_t*)ep.out + o) = lo;
-            *(u32x4_t*)((bf16_t*)ep.out + o + 8) = hi;
-            float g[16];
+            *(u32x4_t*)((bf16_t*)ep.out + o_lo) = lo;
+            *(u32x4_t*)((bf16_t*)ep.out + o_hi) = hi;
+            float gl[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) g[j] = gelu_erf(v[j]);
-            u32x4_t glo = {pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]), pack_bf16x2(g[4], g[5]), pack_bf16x2(g[6], g[7])};
-            u32x4_t ghi = {pack_bf16x2(g[8], g[9]), pack_bf16x2(g[10], g[11]), pack_bf16x2(g[12], g[13]), pack_bf16x2(g[14], g[15])};
-            *(u32x4_t*)((bf16_t*)ep.out2 + o) = glo;
-            *(u32x4_t*)((bf16_t*)ep.out2 + o + 8) = ghi;
+            for (int j = 0; j < 16; ++j) gl[j] = gelu_erf(v[j]);
+            u32x4_t glo = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3]), pack_bf16x2(gl[4], gl[5]), pack_bf16x2(gl[6], gl[7])};
+            u32x4_t ghi = {pack_bf16x2(gl[8], gl[9]), pack_bf16x2(gl[10], gl[11]), pack_bf16x2(gl[12], gl[13]), pack_bf16x2(gl[14], gl[15])};
+            *(u32x4_t*)((bf16_t*)ep.out2 + o_lo) = glo;
+            *(u32x4_t*)((bf16_t*)ep.out2 + o_hi) = ghi;
         } else if (EPI == VA_EPI_F32) {
             if (ep.resid != nullptr) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4_t rv = *(const f32x4_t*)(ep.resid + o + 4 * g);
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4_t rv = *(const f32x4_t*)(ep.resid + (size_t)m * ldc + col(a));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[4 * g + j] += rv[j];
+                    for (int j = 0; j < 4; ++j) v[4 * a + j] += rv[j];
                 }
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *(f32x4_t*)((float*)ep.out + o + 4 * g) = (f32x4_t){v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            for (int a = 0; a < 4; ++a)
+                *(f32x4_t*)((float*)ep.out + (size_t)m * ldc + col(a)) = (f32x4_t){v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3]};
         } else {  // VA_EPI_GELU_BWD
-            const u32x4_t p_lo = *(const u32x4_t*)(ep.aux + o);
-            const u32x4_t p_hi = *(const u32x4_t*)(ep.aux + o + 8);
+            const u32x4_t p_lo = *(const u32x4_t*)(ep.aux + o_lo);
+            const u32x4_t p_hi = *(const u32x4_t*)(ep.aux + o_hi);
             float r[16];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -149,8 +164,8 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
             }
             u32x4_t lo = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
             u32x4_t hi = {pack_bf16x2(r[8], r[9]), pack_bf16x2(r[10], r[11]), pack_bf16x2(r[12], r[13]), pack_bf16x2(r[14], r[15])};
-            *(u32x4_t*)((bf16_t*)ep.out + o) = lo;
-            *(u32x4_t*)((bf16_t*)ep.out + o + 8) = hi;
+            *(u32x4_t*)((bf16_t*)ep.out + o_lo) = lo;
+            *(u32x4_t*)((bf16_t*)ep.out + o_hi) = hi;
         }
     }
 }
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pair_kernel(const bf16_t*
 // ------------------------------------------------------------------------------------------------
 // "ring" loop: 256 x 256 tile, 8 waves (2 x 4), BK = 32 stages in a 5-slot ring (all 160 KiB of LDS).
 // Rows are 64 B (4 chunks); chunk XOR (3 * ((row>>3)&1)) makes the 16x16x32 fragment reads conflict-free.
-// Weight rows are staged in a permuted order (see store_tile_wide) so that the epilogue stores full lines.
+// Weight rows are staged in a permuted order (wide_wrow) so that the epilogue stores whole sectors.
 // ------------------------------------------------------------------------------------------------
 template <int EPI, bool PAIRED>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
@@ -291,10 +306,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
         int grow = m0 + row;
         grow = grow < M ? grow : M - 1;
         xsrc[i] = X + (size_t)grow * ldx + c * 8;
-        // LDS row = wave_n*64 + a*16 + r  holds weight row  wave_n*64 + (r>>2)*16 + a*4 + (r&3)
-        const int r = row & 15, a = (row >> 4) & 3;
-        const int wrow = (row & ~63) + (r >> 2) * 16 + a * 4 + (r & 3);
-        wsrc[i] = W + (size_t)(n0 + wrow) * ldw + c * 8;
+        wsrc[i] = W + (size_t)(n0 + wide_wrow<EPI>(row)) * ldw + c * 8;
     }
     auto stage = [&](int kt, int slot) {
         char* xb = smem + slot * STAGE_BYTES;
@@ -453,7 +465,8 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
         body(P1{}, No{}, 0);
     }
 
-    store_tile_wide<EPI, TM>(acc, ep, M, m0 + wm * 128, n0 + wn * 64, lane);
+    if (m0 + wm * 128 + 128 <= M) store_tile_wide<EPI, TM, true>(acc, ep, M, m0 + wm * 128, n0 + wn * 64, lane);
+    else store_tile_wide<EPI, TM, false>(acc, ep, M, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 int ensure_lds(const void* kern, int bytes, bool* flags) {
