@@ -94,6 +94,12 @@ int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, int64_t Tp, 
  * hd in {64, 128}. */
 int va_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N, int64_t H,
                 int64_t hd, int64_t ldqkv, int64_t ldo, va_stream_t stream);
+/* Same with the predictor's block-causal mask (BlockCausalMask.create_mask, swm:1008-1028, as used by
+ * HybridPredictorBlock swm:975-997): a query of timestep n / tokens_per_timestep attends to every key of the
+ * same and of earlier timesteps.  N must be a whole number of timesteps.  Forward only (inference). */
+int va_attn_fwd_block_causal(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N,
+                             int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t tokens_per_timestep,
+                             va_stream_t stream);
 /* backward of the same: given o, do (bf16, layout of o), lse2, writes dq, dk, dv (layout of q/k/v, ld =
  * lddqkv).  workspace: 5*B*H*N floats, 16-byte aligned (per-query softmax statistics in the two forms the
  * dQ and dK/dV passes consume). */
@@ -127,6 +133,21 @@ int va_ema_update(float* target, const float* online, void* target_bf16, int64_t
  * = sign(pred - target) * grad_scale.  pred/target f32 or bf16 per in_bf16. */
 int va_l1_loss(const void* pred, const void* target, int in_bf16, float* loss_sum, void* grad, int grad_bf16,
                float grad_scale, int64_t n, va_stream_t stream);
+
+/* ---- predictor: gated delta-rule memory (GatedDeltaLayer, swm:431-555), inference form -----------------
+ * Sequential recurrence of _sequential_gated_delta (swm:523-555) for every (batch, head):
+ *   S <- alpha_t * S * (I - beta_t k_t k_t^T) + beta_t v_t k_t^T ;  out_t = S q_t
+ * q,k,v,out: f32 [B, L, H, hd] contiguous; alpha,beta: f32 [B, L, H]; state_in (may be NULL = zeros) and
+ * state_out: f32 [B, H, hd, hd].  hd in {64, 128}. */
+int va_gated_delta_seq(const float* q, const float* k, const float* v, const float* alpha, const float* beta,
+                       const float* state_in, float* out, float* state_out, int64_t B, int64_t L, int64_t H, int64_t hd,
+                       va_stream_t stream);
+/* Causal depthwise conv1d with 4 taps + bias + SiLU over x f32 [B, L, C] (nn.Conv1d(C, C, 4, padding=3,
+ * groups=C) cut to the first L outputs, swm:452-457 / 484-486, then swm:489-491): out[b,t,c] =
+ * silu(bias[c] + sum_i w[c][i] * x[b, t-3+i, c]); with normalize != 0 each row is then divided by
+ * max(||row||_2, 1e-12) (F.normalize over all C channels).  w: f32 [C, 4].  Not in place. */
+int va_dwconv1d_causal_silu(const float* x, const float* w, const float* bias, float* out, int64_t B, int64_t L,
+                            int64_t C, int normalize, va_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -358,3 +358,90 @@ def encoder_flops_per_clip(depth: int, n_tokens: int, dim: int = 1024, patch_k: 
     """Forward FLOPs of one clip: per token per layer 2*D*3D + 2*D*D + 2*2*D*4D + 4*N*D, plus patch embed."""
     per_tok = 2 * dim * 3 * dim + 2 * dim * dim + 4 * dim * 4 * dim + 4 * n_tokens * dim
     return depth * n_tokens * per_tok + 2 * patch_k * dim * n_tokens
+
+
+# ------------------------------------------------------------------------------------------------
+# predictor pieces (swm:431-555, 952-1028)
+# ------------------------------------------------------------------------------------------------
+def gated_delta_sequential(q, k, v, alpha, beta, state=None):
+    """swm:523-555, literally: per step  S <- S @ (alpha*(I - beta*k k^T)) + beta * v k^T ;  o = S q.
+    q,k,v [B,L,H,D]; alpha,beta [B,L,H]; state [B,H,D,D] or None -> (out [B,L,H,D], state)."""
+    B, L, H, D = q.shape
+    S = torch.zeros(B, H, D, D, dtype=q.dtype) if state is None else state.clone()
+    eye = torch.eye(D, dtype=q.dtype)
+    outs = []
+    for t in range(L):
+        kt, vt, qt = k[:, t], v[:, t], q[:, t]
+        a = alpha[:, t, :, None, None]
+        b = beta[:, t, :, None, None]
+        decay = a * (eye - b * (kt[..., :, None] * kt[..., None, :]))
+        S = S @ decay + b * (vt[..., :, None] * kt[..., None, :])
+        outs.append((S @ qt[..., None])[..., 0])
+    return torch.stack(outs, dim=1), S
+
+
+def dwconv1d_causal_silu(x, weight, bias, normalize: bool):
+    """swm:484-491: Conv1d(C, C, 4, padding=3, groups=C) cut to the first L outputs, SiLU, optional
+    F.normalize over the channels.  x [B,L,C]; weight [C,1,4] or [C,4]."""
+    B, L, C = x.shape
+    w = weight.reshape(C, 4)
+    xp = F.pad(x, (0, 0, 3, 0))                       # three zero rows in front
+    y = bias + sum(w[:, i] * xp[:, i:i + L] for i in range(4))
+    y = y * torch.sigmoid(y)
+    return F.normalize(y, p=2, dim=-1) if normalize else y
+
+
+def block_causal_mask(seq_len: int, tokens_per_timestep: int) -> torch.Tensor:
+    """swm:1008-1028: bool [L,L], True = masked; a token sees its own and earlier timesteps.  (Rows of a
+    trailing partial timestep are fully masked by the reference; the model never builds such a length.)"""
+    step = torch.arange(seq_len) // tokens_per_timestep
+    mask = step[None, :] > step[:, None]
+    whole = (seq_len // tokens_per_timestep) * tokens_per_timestep
+    mask[whole:, :] = True
+    return mask
+
+
+def mha_forward(x, P: Dict[str, torch.Tensor], prefix: str, heads: int, attn_mask=None):
+    """nn.MultiheadAttention(batch_first=True) self-attention with in/out biases (swm:959-961, 986-988)."""
+    B, L, D = x.shape
+    hd = D // heads
+    qkv = x @ P[prefix + "in_proj_weight"].t() + P[prefix + "in_proj_bias"]
+    q, k, v = (t.reshape(B, L, heads, hd).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if attn_mask is not None:
+        s = s.masked_fill(attn_mask, float("-inf"))
+    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, D)
+    return o @ P[prefix + "out_proj.weight"].t() + P[prefix + "out_proj.bias"]
+
+
+def gated_delta_layer(x, P: Dict[str, torch.Tensor], prefix: str, heads: int, state=None):
+    """GatedDeltaLayer.forward in its sequential form (swm:468-521)."""
+    B, L, D = x.shape
+    q = dwconv1d_causal_silu(x @ P[prefix + "q_proj.weight"].t(), P[prefix + "q_conv1d.weight"], P[prefix + "q_conv1d.bias"], True)
+    k = dwconv1d_causal_silu(x @ P[prefix + "k_proj.weight"].t(), P[prefix + "k_conv1d.weight"], P[prefix + "k_conv1d.bias"], True)
+    v = dwconv1d_causal_silu(x @ P[prefix + "v_proj.weight"].t(), P[prefix + "v_conv1d.weight"], P[prefix + "v_conv1d.bias"], False)
+    alpha = torch.sigmoid(x @ P[prefix + "a_proj.weight"].t())
+    beta = torch.sigmoid(x @ P[prefix + "b_proj.weight"].t())
+    inner = q.shape[-1]
+    hd = inner // heads
+    v, gate = v[..., :inner], v[..., inner:]
+    out, state = gated_delta_sequential(q.reshape(B, L, heads, hd), k.reshape(B, L, heads, hd), v.reshape(B, L, heads, hd),
+                                        alpha, beta, state)
+    out = out.reshape(B, L, inner) * gate
+    g = x @ P[prefix + "g_proj.weight"].t()
+    out = out * (g * torch.sigmoid(g))
+    out = F.layer_norm(out, (inner,), P[prefix + "o_norm.weight"], P[prefix + "o_norm.bias"], 1e-5)
+    return out @ P[prefix + "o_proj.weight"].t(), state
+
+
+def hybrid_predictor_block(x, P: Dict[str, torch.Tensor], prefix: str, heads: int, use_deltanet: bool,
+                           attn_mask=None, state=None):
+    """HybridPredictorBlock.forward (swm:975-997)."""
+    h = layer_norm(x, P[prefix + "norm1.weight"], P[prefix + "norm1.bias"])
+    x = x + mha_forward(h, P, prefix + "spatial_attn.", heads, attn_mask)
+    if use_deltanet:
+        d, state = gated_delta_layer(x, P, prefix + "temporal_layer.", heads, state)
+        x = x + d
+    h = layer_norm(x, P[prefix + "norm2.weight"], P[prefix + "norm2.bias"])
+    h = gelu_erf(h @ P[prefix + "mlp.0.weight"].t() + P[prefix + "mlp.0.bias"])
+    return x + h @ P[prefix + "mlp.2.weight"].t() + P[prefix + "mlp.2.bias"], state

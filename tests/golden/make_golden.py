@@ -176,6 +176,67 @@ def gen_seed_canary():
          keys=np.array(list(enc.state_dict().keys())))
 
 
+
+def gen_predictor():
+    """Predictor pieces and one whole-model forward (inference), through the reference classes."""
+    # (a) the recurrence alone, with a non-zero incoming state
+    B, L, H, D = 2, 21, 2, 128
+    layer = swm.GatedDeltaLayer(256, num_heads=H, head_dim=D)
+    q = torch.nn.functional.normalize(R.hashed_uniform("golden.gd.q", (B, L, H * D), 1.0), dim=-1).view(B, L, H, D)
+    k = torch.nn.functional.normalize(R.hashed_uniform("golden.gd.k", (B, L, H * D), 1.0), dim=-1).view(B, L, H, D)
+    v = R.hashed_uniform("golden.gd.v", (B, L, H, D), 1.0)
+    alpha = R.hashed_uniform("golden.gd.alpha", (B, L, H), 0.45, 0.5)
+    beta = R.hashed_uniform("golden.gd.beta", (B, L, H), 0.45, 0.5)
+    s0 = R.hashed_uniform("golden.gd.state", (B, H, D, D), 0.1)
+    with torch.no_grad():
+        out, s1 = layer._sequential_gated_delta(q, k, v, alpha, beta, s0.clone())
+        out0, _ = layer._sequential_gated_delta(q, k, v, alpha, beta, None)
+    o_out, o_s1 = R.gated_delta_sequential(q, k, v, alpha, beta, s0)
+    close(o_out, out, "gated delta recurrence out")
+    close(o_s1, s1, "gated delta recurrence state")
+    close(R.gated_delta_sequential(q, k, v, alpha, beta, None)[0], out0, "gated delta recurrence out (zero state)")
+    arrs = dict(gd_out=out, gd_out_zero_state=out0, gd_state_sample=s1[:, :, ::8, ::8])
+
+    # (b) one HybridPredictorBlock with and without the memory layer, block-causal mask, heads 8 (hd 128)
+    dim, heads, tpt, T = 1024, 8, 6, 4
+    Lb = tpt * T
+    x = R.hashed_uniform("golden.pb.x", (2, Lb, dim), 1.0)
+    mask = swm.BlockCausalMask.create_mask(Lb, tpt, x.device)
+    assert torch.equal(mask, R.block_causal_mask(Lb, tpt))
+    for use_dn in (True, False):
+        blk = swm.HybridPredictorBlock(dim, heads, use_deltanet=use_dn).eval()
+        P = R.fill_state_dict_({"pb." + kk: vv for kk, vv in blk.state_dict().items()})
+        blk.load_state_dict({kk[3:]: vv for kk, vv in P.items()})
+        with torch.no_grad():
+            y, st = blk(x, attn_mask=mask)
+        oy, ost = R.hybrid_predictor_block(x, P, "pb.", heads, use_dn, mask)
+        close(oy, y, f"predictor block (deltanet={use_dn})", rtol=1e-4, atol=1e-4)
+        arrs[f"block_out_dn{int(use_dn)}"] = y
+        if use_dn:
+            close(ost, st, "predictor block state", rtol=1e-4, atol=1e-4)
+            arrs["block_state_sample"] = st[:, :, ::8, ::8]
+    arrs["block_tpt"] = tpt
+
+    # (c) the whole model, horizon 2 (img 32, 4 frames: 2 temporal x 4 spatial patches, tokens_per_timestep 6)
+    torch.manual_seed(0)
+    model = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                                    predictor_depth=3, predictor_heads=8).eval()
+    model.load_state_dict(R.fill_state_dict_(model.state_dict()))
+    video = R.hashed_uniform("golden.wm.video", (2, 3, 4, 32, 32), 1.0)
+    actions = R.hashed_uniform("golden.wm.actions", (2, 4, 7), 1.0)
+    states = R.hashed_uniform("golden.wm.states", (2, 4, 7), 1.0)
+    with torch.no_grad():
+        preds, cur, fut = model(video, actions, states, predict_horizon=2)
+    arrs["wm_current_logits"] = cur
+    arrs["wm_future_logits"] = fut
+    arrs["wm_horizon"] = len(preds)
+    for i, p in enumerate(preds):
+        for kk, vv in p.items():
+            arrs[f"wm_pred{i}_{kk}"] = vv
+    arrs["wm_keys"] = np.array(sorted(preds[0].keys()))
+    save("predictor.npz", **arrs)
+
+
 def gen_masking():
     for m in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
         sys.modules.setdefault(m, types.ModuleType(m))
@@ -224,7 +285,11 @@ def gen_masking():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "predictor":     # only the predictor fixture
+        gen_predictor()
+        raise SystemExit(0)
     with torch.enable_grad():
+        gen_predictor()
         gen_rope()
         gen_tubelet()
         gen_attention()

@@ -1,0 +1,156 @@
+"""GPU: predictor kernels (delta-rule recurrence, causal conv, block-causal attention) and the whole-model
+inference forward, against the CPU oracle and the reference's golden outputs (tests/golden/predictor.npz)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 2e-2          # bf16 attention / bf16 encoder against the reference's fp32
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available()
+    from vit_amd import ops
+    from vit_amd import surgical_world_model as swm
+    return ops, swm
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "predictor.npz"), allow_pickle=False)
+
+
+def gd_inputs(B=2, L=21, H=2, D=128):
+    F = torch.nn.functional
+    q = F.normalize(R.hashed_uniform("golden.gd.q", (B, L, H * D), 1.0), dim=-1).view(B, L, H, D)
+    k = F.normalize(R.hashed_uniform("golden.gd.k", (B, L, H * D), 1.0), dim=-1).view(B, L, H, D)
+    v = R.hashed_uniform("golden.gd.v", (B, L, H, D), 1.0)
+    alpha = R.hashed_uniform("golden.gd.alpha", (B, L, H), 0.45, 0.5)
+    beta = R.hashed_uniform("golden.gd.beta", (B, L, H), 0.45, 0.5)
+    s0 = R.hashed_uniform("golden.gd.state", (B, H, D, D), 0.1)
+    return q, k, v, alpha, beta, s0
+
+
+def test_gated_delta_matches_reference_vectors(env, gold):
+    ops, _ = env
+    q, k, v, a, b, s0 = gd_inputs()
+    out, s1 = ops.gated_delta_seq(q.cuda(), k.cuda(), v.cuda(), a.cuda(), b.cuda(), s0.cuda())
+    assert (out.cpu() - torch.from_numpy(gold["gd_out"])).abs().max().item() < 2e-5
+    assert (s1.cpu()[:, :, ::8, ::8] - torch.from_numpy(gold["gd_state_sample"])).abs().max().item() < 2e-5
+    out0, _ = ops.gated_delta_seq(q.cuda(), k.cuda(), v.cuda(), a.cuda(), b.cuda(), None)
+    assert (out0.cpu() - torch.from_numpy(gold["gd_out_zero_state"])).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,L,H,D", [(1, 1, 1, 128), (3, 16, 8, 128), (2, 33, 3, 64), (1, 200, 8, 128)])
+def test_gated_delta_vs_oracle(env, B, L, H, D):
+    ops, _ = env
+    F = torch.nn.functional
+    q = F.normalize(R.hashed_uniform("t.gd.q", (B, L, H, D), 1.0), dim=-1)
+    k = F.normalize(R.hashed_uniform("t.gd.k", (B, L, H, D), 1.0), dim=-1)
+    v = R.hashed_uniform("t.gd.v", (B, L, H, D), 1.0)
+    a = R.hashed_uniform("t.gd.a", (B, L, H), 0.5, 0.5)
+    b = R.hashed_uniform("t.gd.b", (B, L, H), 0.5, 0.5)
+    ref_o, ref_s = R.gated_delta_sequential(q, k, v, a, b, None)
+    out, st = ops.gated_delta_seq(q.cuda(), k.cuda(), v.cuda(), a.cuda(), b.cuda())
+    assert (out.cpu() - ref_o).abs().max().item() < 5e-5
+    assert (st.cpu() - ref_s).abs().max().item() < 5e-5
+    # a sequence processed in two calls, state carried over, equals one call (the rollout's usage)
+    cut = max(1, L // 3)
+    o1, s1 = ops.gated_delta_seq(q[:, :cut].contiguous().cuda(), k[:, :cut].contiguous().cuda(), v[:, :cut].contiguous().cuda(),
+                                 a[:, :cut].contiguous().cuda(), b[:, :cut].contiguous().cuda())
+    if cut < L:
+        o2, s2 = ops.gated_delta_seq(q[:, cut:].contiguous().cuda(), k[:, cut:].contiguous().cuda(), v[:, cut:].contiguous().cuda(),
+                                     a[:, cut:].contiguous().cuda(), b[:, cut:].contiguous().cuda(), s1)
+        assert torch.allclose(torch.cat([o1, o2], dim=1), out, atol=1e-5) and torch.allclose(s2, st, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,L,C,norm", [(2, 1, 1024, True), (2, 7, 1024, True), (3, 50, 2048, False), (1, 5, 256, True)])
+def test_dwconv_silu_vs_oracle(env, B, L, C, norm):
+    ops, _ = env
+    x = R.hashed_uniform("t.dw.x", (B, L, C), 2.0)
+    w = R.hashed_uniform("t.dw.w", (C, 1, 4), 0.5)
+    bias = R.hashed_uniform("t.dw.b", (C,), 0.1)
+    ref = R.dwconv1d_causal_silu(x, w, bias, norm)
+    out = ops.dwconv1d_causal_silu(x.cuda(), w.cuda(), bias.cuda(), norm)
+    assert (out.cpu() - ref).abs().max().item() < 2e-6 * (1 if norm else 10)
+
+
+@pytest.mark.parametrize("B,T,tpt,H", [(2, 4, 6, 8), (1, 9, 18, 8), (2, 5, 66, 16), (1, 16, 129, 8)])
+def test_block_causal_attention_vs_oracle(env, B, T, tpt, H):
+    ops, _ = env
+    D, L = 1024, T * tpt
+    hd = D // H
+    qkv = (R.hashed_uniform("t.bc.qkv", (B * L, 3 * D), 1.5)).to(torch.bfloat16)
+    out = torch.empty(B * L, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H, L, device="cuda")
+    ops.attn_fwd(qkv.cuda(), B, L, H, out, lse, tokens_per_timestep=tpt)
+    q, k, v = (t.float().view(B, L, H, hd).transpose(1, 2) for t in qkv.split(D, dim=-1))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    s = s.masked_fill(R.block_causal_mask(L, tpt), float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, D)
+    assert rel(out, ref) < 8e-3
+    ref_lse = torch.logsumexp(s, -1) / math.log(2.0)
+    assert (lse.cpu().view(B, H, L) - ref_lse).abs().max().item() < 2e-2
+
+
+def test_block_causal_rejects_partial_timestep(env):
+    ops, _ = env
+    from vit_amd._lib import VitAmdError
+    qkv = torch.zeros(10, 3 * 1024, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(VitAmdError):
+        ops.attn_fwd(qkv, 1, 10, 8, torch.empty(10, 1024, dtype=torch.bfloat16, device="cuda"),
+                     torch.empty(8, 10, device="cuda"), tokens_per_timestep=4)
+
+
+def test_predictor_block_matches_reference_vectors(env, gold):
+    _, swm = env
+    dim, heads, tpt, T = 1024, 8, int(gold["block_tpt"]), 4
+    L = tpt * T
+    x = R.hashed_uniform("golden.pb.x", (2, L, dim), 1.0).cuda()
+    mask = swm.BlockCausalMask.create_mask(L, tpt, x.device)
+    for use_dn in (True, False):
+        blk = swm.HybridPredictorBlock(dim, heads, use_deltanet=use_dn).eval()
+        P = R.fill_state_dict_({"pb." + k: v for k, v in blk.state_dict().items()})
+        blk.load_state_dict({k[3:]: v for k, v in P.items()})
+        blk = blk.cuda()
+        with torch.no_grad():
+            y, st = blk(x, attn_mask=mask)
+        assert rel(y, torch.from_numpy(gold[f"block_out_dn{int(use_dn)}"])) < REL_TOL
+        if use_dn:
+            assert rel(st[:, :, ::8, ::8], torch.from_numpy(gold["block_state_sample"])) < REL_TOL
+        # the autograd formulation of the same block (torch ops) agrees with the kernel path
+        xg = x.clone().requires_grad_(True)
+        y2, _ = blk(xg, attn_mask=mask)
+        assert rel(y2.detach(), y) < REL_TOL
+
+
+def test_world_model_forward_matches_reference_vectors(env, gold):
+    _, swm = env
+    torch.manual_seed(0)
+    model = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                                    predictor_depth=3, predictor_heads=8).eval()
+    model.load_state_dict(R.fill_state_dict_(model.state_dict()))
+    model = model.cuda()
+    video = R.hashed_uniform("golden.wm.video", (2, 3, 4, 32, 32), 1.0).cuda()
+    actions = R.hashed_uniform("golden.wm.actions", (2, 4, 7), 1.0).cuda()
+    states = R.hashed_uniform("golden.wm.states", (2, 4, 7), 1.0).cuda()
+    with torch.no_grad():
+        preds, cur, fut = model(video, actions, states, predict_horizon=2)
+    assert len(preds) == int(gold["wm_horizon"])
+    assert sorted(preds[0].keys()) == [str(k) for k in gold["wm_keys"]]
+    assert rel(cur, torch.from_numpy(gold["wm_current_logits"])) < REL_TOL
+    assert rel(fut, torch.from_numpy(gold["wm_future_logits"])) < REL_TOL
+    for i, p in enumerate(preds):
+        for k, v in p.items():
+            assert rel(v, torch.from_numpy(gold[f"wm_pred{i}_{k}"])) < 2 * REL_TOL, (i, k)

@@ -34,6 +34,7 @@ SIGNATURES = {
     "va_layernorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
     "va_rope3d_qk_inplace": (ci, [vp, vp, i64, i64, i64, i64, ci, vp]),
     "va_attn_fwd": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp]),
+    "va_attn_fwd_block_causal": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
     "va_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
     "va_cast_f32_bf16": (ci, [vp, vp, i64, vp]),
     "va_cast_transpose_f32_bf16": (ci, [vp, vp, i64, i64, vp]),
@@ -42,6 +43,8 @@ SIGNATURES = {
     "va_token_scatter": (ci, [vp, vp, vp, i64, i64, i64, i64, vp]),
     "va_ema_update": (ci, [vp, vp, vp, i64, cf, vp]),
     "va_l1_loss": (ci, [vp, vp, ci, vp, vp, ci, cf, i64, vp]),
+    "va_gated_delta_seq": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    "va_dwconv1d_causal_silu": (ci, [vp, vp, vp, vp, i64, i64, i64, ci, vp]),
 }
 
 

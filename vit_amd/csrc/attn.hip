@@ -150,11 +150,15 @@ constexpr int fwd_ring_slots(int hd) { return hd == 64 ? 3 : 2; }
 //    (probabilities then stay below 2^THR, harmless in bf16 x f32), so rescaling O is a rare,
 //    wave-uniform branch taken before any score of the tile is exponentiated.
 // ------------------------------------------------------------------------------------------------
-template <int HD, bool RAGGED>
+// MODE: which keys a query sees.  0: all, N a multiple of 64.  1: all, ragged N.  2: block-causal, a query of
+// timestep s = n / tpt sees the keys of timesteps <= s (the predictor's mask, swm:1008-1028); N % tpt == 0.
+// Modes 1 and 2 are one mechanism: a per-lane key limit, applied only in tiles that reach past it.
+template <int HD, int MODE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE2, int N, int H, int64_t ld, int64_t ldo,
-                                                       float c) {
+                                                       float c, int tpt) {
+    constexpr bool RAGGED = MODE != 0;
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
     constexpr int NBUF = fwd_ring_slots(HD), AHEAD = NBUF - 1, LOADS = 2 * TileSrc<HD>::PER_THREAD;
     constexpr float THR = 6.0f;
@@ -189,7 +193,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     for (int i = 0; i < 16; ++i) negm[i] = 0.f;
     float m = 0.f, l = 0.f;
 
-    const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
+    int klim = N;                                   // this lane's query sees keys [0, klim)
+    int nt = (N + TILE_ROWS - 1) / TILE_ROWS;       // tiles the workgroup walks (uniform)
+    if (MODE == 2) {
+        klim = (qrow_c / tpt + 1) * tpt;
+        int q_last = blockIdx.x * 128 + 127;
+        q_last = q_last < N ? q_last : N - 1;
+        nt = ((q_last / tpt + 1) * tpt + TILE_ROWS - 1) / TILE_ROWS;
+    }
     TileSrc<HD> ts;
     ts.init(ld, tid);
     auto stage = [&](int tile, int slot) {
@@ -224,32 +235,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         const char* kt = smem + SLOT * 2 * TB;
         const char* vt = kt + TB;
 
-        bf16x8_t kf[2][KS];   // every LDS read of a phase is issued before its first MFMA
+        // hd 64: every LDS read of a phase is issued before its first MFMA (the fragments fit the register
+        // file); hd 128: fragments are read next to their use.
+        constexpr bool PRELOAD = HD == 64;
+        bf16x8_t kf[2][KS];
+        if (PRELOAD) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = row_frag<HD>(kt, kb * 32, ks, lane);
+                for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = row_frag<HD>(kt, kb * 32, ks, lane);
+        }
         f32x16_t st[2];   // scores of this tile relative to the running maximum, log2 units
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            st[kb] = mfma32(kf[kb][0], qf[0], negm);
+            st[kb] = mfma32(PRELOAD ? kf[kb][0] : row_frag<HD>(kt, kb * 32, 0, lane), qf[0], negm);
 #pragma unroll
-            for (int ks = 1; ks < KS; ++ks) st[kb] = mfma32(kf[kb][ks], qf[ks], st[kb]);
+            for (int ks = 1; ks < KS; ++ks)
+                st[kb] = mfma32(PRELOAD ? kf[kb][ks] : row_frag<HD>(kt, kb * 32, ks, lane), qf[ks], st[kb]);
         }
         bf16x8_t vf[2][2][CB];
+        if (PRELOAD) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) vf[kb][s][cb] = tr_frag<HD>(vt, kb * 32 + 16 * s, cb, lane);
+                    for (int cb = 0; cb < CB; ++cb) vf[kb][s][cb] = tr_frag<HD>(vt, kb * 32 + 16 * s, cb, lane);
+        }
         if (t + AHEAD < nt) stage(t + AHEAD, (SLOT + AHEAD) % NBUF);
-        if (RAGGED && t == nt - 1) {   // RAGGED <=> N % 64 != 0: only that build carries the selects
+        if (MODE != 0 && __any((t + 1) * TILE_ROWS > klim)) {   // only builds with a key limit carry the selects
+            const int rel = klim - t * TILE_ROWS;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (t * TILE_ROWS + kb * 32 + acc32_row(i, h) >= N) st[kb][i] = -INFINITY;
+                    if (kb * 32 + acc32_row(i, h) >= rel) st[kb][i] = -INFINITY;
         }
         float mq[4];
 #pragma unroll
@@ -292,7 +312,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             for (int s = 0; s < 2; ++s) {
                 const bf16x8_t pf = pack_acc(st[kb], s);
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) o[cb] = mfma32(vf[kb][s][cb], pf, o[cb]);
+                for (int cb = 0; cb < CB; ++cb)
+                    o[cb] = mfma32(PRELOAD ? vf[kb][s][cb] : tr_frag<HD>(vt, kb * 32 + 16 * s, cb, lane), pf, o[cb]);
             }
         VA_STAMP(2)
     };
@@ -623,22 +644,25 @@ int check_common(const char* who, int64_t B, int64_t N, int64_t H, int64_t hd, i
     return VA_OK;
 }
 
-template <int HD>
-int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
-               int64_t ld, int64_t ldo, hipStream_t stream) {
+template <int HD, int MODE>
+int fwd_launch_mode(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
+                    int64_t ld, int64_t ldo, int tpt, hipStream_t stream) {
     constexpr int LDS = fwd_ring_slots(HD) * 2 * TILE_ROWS * HD * 2;
-    static bool flags[2][64] = {};
+    static bool flags[64] = {};
     const float c = 1.4426950408889634f / sqrtf((float)HD);
     const dim3 grid((N + 127) / 128, B * H);
-    if (N % TILE_ROWS) {
-        if (int e = set_lds(attn_fwd_kernel<HD, true>, LDS, flags[1], "va_attn_fwd")) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), LDS, stream, q, k, v, o, lse2, N, H, ld, ldo, c);
-    } else {
-        if (int e = set_lds(attn_fwd_kernel<HD, false>, LDS, flags[0], "va_attn_fwd")) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), LDS, stream, q, k, v, o, lse2, N, H, ld, ldo, c);
-    }
+    if (int e = set_lds(attn_fwd_kernel<HD, MODE>, LDS, flags, "va_attn_fwd")) return e;
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, MODE>), grid, dim3(256), LDS, stream, q, k, v, o, lse2, N, H, ld, ldo, c, tpt);
     VA_CHECK_LAUNCH("va_attn_fwd");
     return VA_OK;
+}
+
+template <int HD>
+int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
+               int64_t ld, int64_t ldo, int tpt, hipStream_t stream) {
+    if (tpt > 0) return fwd_launch_mode<HD, 2>(q, k, v, o, lse2, B, N, H, ld, ldo, tpt, stream);
+    if (N % TILE_ROWS) return fwd_launch_mode<HD, 1>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, stream);
+    return fwd_launch_mode<HD, 0>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, stream);
 }
 
 template <int HD>
@@ -686,16 +710,31 @@ int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* 
 
 }  // namespace
 
-extern "C" int va_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N,
-                           int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, hipStream_t stream) {
-    VA_CHECK_ARG(q && k && v && o && lse2, "va_attn_fwd: null operand");
-    if (int e = check_common("va_attn_fwd", B, N, H, hd, ldqkv, ldo)) return e;
-    VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "va_attn_fwd: misaligned operand");
+static int attn_fwd_entry(const char* who, const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B,
+                          int64_t N, int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t tpt, hipStream_t stream) {
+    VA_CHECK_ARG(q && k && v && o && lse2, "%s: null operand", who);
+    if (int e = check_common(who, B, N, H, hd, ldqkv, ldo)) return e;
+    VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "%s: misaligned operand", who);
     if (hd == 64)
         return fwd_launch<64>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, (int)B, (int)N,
-                              (int)H, ldqkv, ldo, stream);
+                              (int)H, ldqkv, ldo, (int)tpt, stream);
     return fwd_launch<128>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, (int)B, (int)N, (int)H,
-                           ldqkv, ldo, stream);
+                           ldqkv, ldo, (int)tpt, stream);
+}
+
+extern "C" int va_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N,
+                           int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, hipStream_t stream) {
+    return attn_fwd_entry("va_attn_fwd", q, k, v, o, lse2, B, N, H, hd, ldqkv, ldo, 0, stream);
+}
+
+extern "C" int va_attn_fwd_block_causal(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B,
+                                        int64_t N, int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo,
+                                        int64_t tokens_per_timestep, hipStream_t stream) {
+    VA_CHECK_ARG(tokens_per_timestep > 0 && N % tokens_per_timestep == 0,
+                 "va_attn_fwd_block_causal: N=%lld must be a whole number of timesteps of %lld tokens", (long long)N,
+                 (long long)tokens_per_timestep);
+    return attn_fwd_entry("va_attn_fwd_block_causal", q, k, v, o, lse2, B, N, H, hd, ldqkv, ldo, tokens_per_timestep,
+                          stream);
 }
 
 extern "C" int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,

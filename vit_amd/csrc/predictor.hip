@@ -1,0 +1,188 @@
+// Kernels of the predictor's gated delta-rule memory layer (inference form).
+//
+//  * gated_delta_kernel: the sequential recurrence of swm:523-555,
+//        S <- alpha_t * S * (I - beta_t k_t k_t^T) + beta_t v_t k_t^T,      o_t = S q_t
+//    evaluated in its rank-1 form  sk = S k;  S <- alpha*S + beta*(v - alpha*sk) k^T  (no hd^3 products).
+//    One workgroup per (batch, head); lane i keeps row i of the hd x hd state in registers for the whole
+//    sequence, so a step is two 128-long dot products and one rank-1 update per lane with no cross-lane
+//    traffic.  k/q/v/alpha/beta of 16 steps at a time are staged in LDS (double-buffered, direct-to-LDS
+//    loads) and read back as broadcasts.
+//  * dwconv_silu_kernel: causal depthwise conv1d (4 taps, swm:452-457 with the [..., :L] cut of swm:484-486)
+//    + bias + SiLU, optionally followed by the row-wise L2 normalisation of swm:489-490.
+#include "common.h"
+
+namespace {
+
+constexpr int GD_T = 16;   // steps per staged chunk
+
+template <int HD>
+__global__ __launch_bounds__(HD) void gated_delta_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                         const float* __restrict__ V, const float* __restrict__ ALPHA,
+                                                         const float* __restrict__ BETA,
+                                                         const float* __restrict__ STATE_IN, float* __restrict__ OUT,
+                                                         float* __restrict__ STATE_OUT, int L, int H) {
+    constexpr int WAVES = HD / 64;
+    constexpr int ROWS_PER_PASS = WAVES * 64 * 4 / HD;          // rows one pass of 16-byte lanes covers
+    constexpr int PASSES = GD_T / ROWS_PER_PASS;
+    __shared__ __attribute__((aligned(16))) float ks[2][GD_T][HD];
+    __shared__ __attribute__((aligned(16))) float qs[2][GD_T][HD];
+    __shared__ __attribute__((aligned(16))) float vs[2][GD_T][HD];
+    __shared__ float ab[2][2][GD_T];
+    const int i = threadIdx.x, lane = i & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int64_t row_stride = (int64_t)H * HD;
+    const float* qb = Q + (int64_t)b * L * row_stride + h * HD;
+    const float* kb = K + (int64_t)b * L * row_stride + h * HD;
+    const float* vb = V + (int64_t)b * L * row_stride + h * HD;
+    const float* ab_src[2] = {ALPHA + (int64_t)b * L * H + h, BETA + (int64_t)b * L * H + h};
+
+    float S[HD];
+    if (STATE_IN != nullptr) {
+        const float* src = STATE_IN + ((int64_t)bh * HD + i) * HD;
+#pragma unroll
+        for (int j = 0; j < HD; j += 4) *(f32x4_t*)(S + j) = *(const f32x4_t*)(src + j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < HD; ++j) S[j] = 0.f;
+    }
+
+    const int r_in_pass = i * 4 / HD, col = (i * 4) % HD;     // this lane's 16 bytes inside a pass
+    auto stage = [&](int chunk, int buf) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            int t = chunk * GD_T + p * ROWS_PER_PASS + r_in_pass;
+            t = t < L ? t : L - 1;
+            const int64_t off = (int64_t)t * row_stride + col;
+            const int dst = (p * ROWS_PER_PASS * HD + wave * 256) * 4;     // wave base; lanes land 16 bytes apart
+            glds16(kb + off, (char*)&ks[buf][0][0] + dst);
+            glds16(qb + off, (char*)&qs[buf][0][0] + dst);
+            glds16(vb + off, (char*)&vs[buf][0][0] + dst);
+        }
+        if (i < 2 * GD_T) {
+            const int which = i / GD_T, tt = i % GD_T;
+            int t = chunk * GD_T + tt;
+            t = t < L ? t : L - 1;
+            ab[buf][which][tt] = ab_src[which][(int64_t)t * H];
+        }
+    };
+
+    const int chunks = (L + GD_T - 1) / GD_T;
+    stage(0, 0);
+    for (int c = 0; c < chunks; ++c) {
+        const int buf = c & 1;
+        wait_vm0();
+        __syncthreads();                       // chunk c is in LDS; everybody is done with chunk c-1
+        if (c + 1 < chunks) stage(c + 1, buf ^ 1);
+        const int steps = (L - c * GD_T) < GD_T ? (L - c * GD_T) : GD_T;
+        for (int t = 0; t < steps; ++t) {
+            const float a = ab[buf][0][t], bt = ab[buf][1][t];
+            const float vi = vs[buf][t][i];
+            float kk[HD];
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < HD; j += 4) {
+                *(f32x4_t*)(kk + j) = *(const f32x4_t*)&ks[buf][t][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(S[j + e], kk[j + e], acc[e]);
+            }
+            const float sk = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            const float cu = bt * (vi - a * sk);
+            float oc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < HD; j += 4) {
+                const f32x4_t q4 = *(const f32x4_t*)&qs[buf][t][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    S[j + e] = fmaf(cu, kk[j + e], a * S[j + e]);
+                    oc[e] = fmaf(S[j + e], q4[e], oc[e]);
+                }
+            }
+            OUT[((int64_t)b * L + c * GD_T + t) * row_stride + h * HD + i] = (oc[0] + oc[1]) + (oc[2] + oc[3]);
+        }
+    }
+    float* dst = STATE_OUT + ((int64_t)bh * HD + i) * HD;
+#pragma unroll
+    for (int j = 0; j < HD; j += 4) *(f32x4_t*)(dst + j) = *(const f32x4_t*)(S + j);
+}
+
+// One wave per (batch, time) row of C channels; lane owns channels 4*lane + 256*m.
+__global__ __launch_bounds__(256) void dwconv_silu_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                          const float* __restrict__ BIAS, float* __restrict__ OUT,
+                                                          int64_t rows, int L, int C, int normalize) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int t = (int)(row % L);
+    const float* x = X + row * C;
+    float* out = OUT + row * C;
+    float ss = 0.f;
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        f32x4_t acc = *(const f32x4_t*)(BIAS + c0);
+        f32x4_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = *(const f32x4_t*)(W + (int64_t)(c0 + e) * 4);   // taps of channel c0+e
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            const int back = 3 - tap;                     // tap i multiplies x[t - 3 + i]
+            if (t - back < 0) continue;
+            const f32x4_t xv = *(const f32x4_t*)(x - (int64_t)back * C + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][tap], xv[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] = acc[e] / (1.0f + __expf(-acc[e]));     // SiLU
+            ss = fmaf(acc[e], acc[e], ss);
+        }
+        *(f32x4_t*)(out + c0) = acc;
+    }
+    if (normalize) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize: x / max(||x||, eps)
+        for (int c0 = lane * 4; c0 < C; c0 += 256) {
+            f32x4_t v = *(const f32x4_t*)(out + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= inv;
+            *(f32x4_t*)(out + c0) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int va_gated_delta_seq(const float* q, const float* k, const float* v, const float* alpha, const float* beta,
+                                  const float* state_in, float* out, float* state_out, int64_t B, int64_t L, int64_t H,
+                                  int64_t hd, hipStream_t stream) {
+    VA_CHECK_ARG(q && k && v && alpha && beta && out && state_out, "va_gated_delta_seq: null operand");
+    VA_CHECK_ARG(B > 0 && L > 0 && H > 0, "va_gated_delta_seq: empty problem");
+    VA_CHECK_ARG(hd == 64 || hd == 128, "va_gated_delta_seq: head dim %lld not supported (64 or 128)", (long long)hd);
+    VA_CHECK_ARG(B * H < (1ll << 31) && L < (1ll << 31), "va_gated_delta_seq: problem too large");
+    VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)state_out | (uintptr_t)state_in) % 16 == 0,
+                 "va_gated_delta_seq: misaligned operand");
+    if (hd == 128)
+        hipLaunchKernelGGL(gated_delta_kernel<128>, dim3((unsigned)(B * H)), dim3(128), 0, stream, q, k, v, alpha, beta,
+                           state_in, out, state_out, (int)L, (int)H);
+    else
+        hipLaunchKernelGGL(gated_delta_kernel<64>, dim3((unsigned)(B * H)), dim3(64), 0, stream, q, k, v, alpha, beta,
+                           state_in, out, state_out, (int)L, (int)H);
+    VA_CHECK_LAUNCH("va_gated_delta_seq");
+    return VA_OK;
+}
+
+extern "C" int va_dwconv1d_causal_silu(const float* x, const float* w, const float* bias, float* out, int64_t B,
+                                       int64_t L, int64_t C, int normalize, hipStream_t stream) {
+    VA_CHECK_ARG(x && w && bias && out, "va_dwconv1d_causal_silu: null operand");
+    VA_CHECK_ARG(B > 0 && L > 0 && C > 0 && C % 4 == 0, "va_dwconv1d_causal_silu: C=%lld must be a positive multiple of 4",
+                 (long long)C);
+    VA_CHECK_ARG(x != out, "va_dwconv1d_causal_silu: cannot run in place (a row reads its three predecessors)");
+    VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out) % 16 == 0,
+                 "va_dwconv1d_causal_silu: misaligned operand");
+    const int64_t rows = B * L;
+    VA_CHECK_ARG(rows < (1ll << 33) && L < (1ll << 31) && C < (1ll << 31), "va_dwconv1d_causal_silu: problem too large");
+    hipLaunchKernelGGL(dwconv_silu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, bias, out, rows,
+                       (int)L, (int)C, normalize);
+    VA_CHECK_LAUNCH("va_dwconv1d_causal_silu");
+    return VA_OK;
+}

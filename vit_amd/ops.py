@@ -177,8 +177,10 @@ def rope3d_qk_(qkv: torch.Tensor, tables: torch.Tensor, grid: Tuple[int, int, in
 
 
 # ------------------------------------------------------------------ attention
-def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2: torch.Tensor):
-    """qkv: packed [B*N, 3*D] bf16 (q | k | v thirds); out [B*N, D] bf16; lse2 [B*H, N] f32."""
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2: torch.Tensor,
+             tokens_per_timestep: int = 0):
+    """qkv: packed [B*N, 3*D] bf16 (q | k | v thirds); out [B*N, D] bf16; lse2 [B*H, N] f32.
+    tokens_per_timestep > 0 selects the predictor's block-causal mask (forward only)."""
     _need(qkv, BF16, "qkv"); _need(out, BF16, "out"); _need(lse2, F32, "lse2")
     M, W3 = qkv.shape
     D = W3 // 3
@@ -186,8 +188,12 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2:
         raise ValueError("attn_fwd: inconsistent shapes")
     hd = D // H
     es = qkv.element_size()
-    check(_lib.load().va_attn_fwd(qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out),
-                                  _p(lse2), B, N, H, hd, _ld(qkv), _ld(out), _stream()), "va_attn_fwd")
+    ptrs = (qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out), _p(lse2))
+    if tokens_per_timestep > 0:
+        check(_lib.load().va_attn_fwd_block_causal(*ptrs, B, N, H, hd, _ld(qkv), _ld(out), tokens_per_timestep,
+                                                   _stream()), "va_attn_fwd_block_causal")
+    else:
+        check(_lib.load().va_attn_fwd(*ptrs, B, N, H, hd, _ld(qkv), _ld(out), _stream()), "va_attn_fwd")
     return out
 
 
@@ -205,6 +211,39 @@ def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int):
                                   dqkv.data_ptr() + 2 * D * es, B, N, H, hd, _ld(qkv), _ld(out), _ld(dqkv), _stream()),
           "va_attn_bwd")
     return dqkv
+
+
+# ------------------------------------------------------------------ predictor (inference)
+def gated_delta_seq(q, k, v, alpha, beta, state=None):
+    """q,k,v f32 [B,L,H,hd]; alpha,beta f32 [B,L,H]; state f32 [B,H,hd,hd] or None -> (out [B,L,H,hd], new state)."""
+    for name, x in (("q", q), ("k", k), ("v", v), ("alpha", alpha), ("beta", beta)):
+        _need(x, F32, name)
+        if not x.is_contiguous():
+            raise ValueError(f"gated_delta_seq: {name} must be contiguous")
+    B, L, H, hd = q.shape
+    if k.shape != q.shape or v.shape != q.shape or tuple(alpha.shape) != (B, L, H) or tuple(beta.shape) != (B, L, H):
+        raise ValueError("gated_delta_seq: inconsistent shapes")
+    if state is not None:
+        _need(state, F32, "state")
+        if tuple(state.shape) != (B, H, hd, hd) or not state.is_contiguous():
+            raise ValueError("gated_delta_seq: state must be contiguous [B,H,hd,hd]")
+    out = torch.empty_like(q)
+    new_state = torch.empty(B, H, hd, hd, dtype=F32, device=q.device)
+    check(_lib.load().va_gated_delta_seq(_p(q), _p(k), _p(v), _p(alpha), _p(beta), None if state is None else _p(state),
+                                         _p(out), _p(new_state), B, L, H, hd, _stream()), "va_gated_delta_seq")
+    return out, new_state
+
+
+def dwconv1d_causal_silu(x, weight, bias, normalize: bool):
+    """x f32 [B,L,C]; weight f32 [C,1,4] (nn.Conv1d layout) or [C,4]; bias [C] -> silu(causal conv) [, row-L2-normalised]."""
+    _need(x, F32, "x"); _need(weight, F32, "weight"); _need(bias, F32, "bias")
+    B, L, C = x.shape
+    if weight.numel() != 4 * C or bias.numel() != C or not (x.is_contiguous() and weight.is_contiguous()):
+        raise ValueError("dwconv1d_causal_silu: inconsistent shapes")
+    out = torch.empty_like(x)
+    check(_lib.load().va_dwconv1d_causal_silu(_p(x), _p(weight), _p(bias), _p(out), B, L, C, int(bool(normalize)),
+                                              _stream()), "va_dwconv1d_causal_silu")
+    return out
 
 
 # ------------------------------------------------------------------ casts

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from ._lib import VitAmdError
 from .encoder_engine import EncoderConfig, EncoderEngine, encoder_param_names
 
@@ -222,8 +223,15 @@ class VideoViTEncoder(nn.Module):
 
 
 # =====================================================================================================
-# predictor side (torch ops on the device; not yet on hand-written kernels)
+# predictor side.  Inference (no autograd graph, tensors on the device) runs the memory layer's causal
+# conv + SiLU (+ normalise), the delta-rule recurrence and the block-causal attention on the HIP kernels;
+# projections and the small heads are library GEMMs through torch.  With autograd the torch formulation of
+# the same arithmetic is used (the predictor is not trained by the stage-1 scripts).
 # =====================================================================================================
+def _hip_inference(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
+
+
 class GatedDeltaLayer(nn.Module):
     """Gated delta-rule memory layer (swm:431-555).  Only the sequential recurrence is provided: it is the
     form inference uses and the one the reference's other ("parallel") path fails to reproduce."""
@@ -267,14 +275,23 @@ class GatedDeltaLayer(nn.Module):
 
     def forward(self, x, state=None, use_parallel=None):
         B, L, _ = x.shape
-        q = F.normalize(self.silu(self._causal_conv(self.q_conv1d, self.q_proj(x))), p=2, dim=-1)
-        k = F.normalize(self.silu(self._causal_conv(self.k_conv1d, self.k_proj(x))), p=2, dim=-1)
-        v = self.silu(self._causal_conv(self.v_conv1d, self.v_proj(x)))
-        alpha, beta = torch.sigmoid(self.a_proj(x)), torch.sigmoid(self.b_proj(x))
         H, Dh = self.num_heads, self.head_dim
-        v, v_gate = v.chunk(2, dim=-1)
-        out, new_state = self._sequential_gated_delta(q.view(B, L, H, Dh), k.view(B, L, H, Dh), v.view(B, L, H, Dh),
-                                                      alpha, beta, state)
+        alpha, beta = torch.sigmoid(self.a_proj(x)), torch.sigmoid(self.b_proj(x))
+        if _hip_inference(x) and Dh in (64, 128):
+            q = ops.dwconv1d_causal_silu(self.q_proj(x), self.q_conv1d.weight, self.q_conv1d.bias, True)
+            k = ops.dwconv1d_causal_silu(self.k_proj(x), self.k_conv1d.weight, self.k_conv1d.bias, True)
+            v = ops.dwconv1d_causal_silu(self.v_proj(x), self.v_conv1d.weight, self.v_conv1d.bias, False)
+            v, v_gate = v.chunk(2, dim=-1)
+            out, new_state = ops.gated_delta_seq(q.view(B, L, H, Dh), k.view(B, L, H, Dh),
+                                                 v.contiguous().view(B, L, H, Dh), alpha.contiguous(), beta.contiguous(),
+                                                 None if state is None else state.contiguous())
+        else:
+            q = F.normalize(self.silu(self._causal_conv(self.q_conv1d, self.q_proj(x))), p=2, dim=-1)
+            k = F.normalize(self.silu(self._causal_conv(self.k_conv1d, self.k_proj(x))), p=2, dim=-1)
+            v = self.silu(self._causal_conv(self.v_conv1d, self.v_proj(x)))
+            v, v_gate = v.chunk(2, dim=-1)
+            out, new_state = self._sequential_gated_delta(q.view(B, L, H, Dh), k.view(B, L, H, Dh), v.view(B, L, H, Dh),
+                                                          alpha, beta, state)
         out = (out * v_gate.view(B, L, H, Dh)).reshape(B, L, -1) * self.silu(self.g_proj(x))
         return self.o_proj(self.o_norm(out)), new_state
 
@@ -338,7 +355,15 @@ class HybridPredictorBlock(nn.Module):
         a = self.spatial_attn
         B, L, D = h.shape
         H = a.num_heads
-        qkv = F.linear(h, a.in_proj_weight, a.in_proj_bias).view(B, L, 3, H, D // H).permute(2, 0, 3, 1, 4)
+        qkv = F.linear(h, a.in_proj_weight, a.in_proj_bias)
+        tpt = 0 if attn_mask is None else getattr(attn_mask, "tokens_per_timestep", -1)
+        if _hip_inference(h) and D // H in (64, 128) and tpt >= 0 and (tpt == 0 or L % tpt == 0):
+            # packed [q | k | v] rows are exactly the attention kernel's layout; the mask is its block-causal mode
+            o = torch.empty(B * L, D, dtype=torch.bfloat16, device=h.device)
+            lse = torch.empty(B * H, L, dtype=torch.float32, device=h.device)
+            ops.attn_fwd(qkv.reshape(B * L, 3 * D).to(torch.bfloat16), B, L, H, o, lse, tokens_per_timestep=tpt)
+            return a.out_proj(o.view(B, L, D).float())
+        qkv = qkv.view(B, L, 3, H, D // H).permute(2, 0, 3, 1, 4)
         allowed = None if attn_mask is None else ~attn_mask            # reference: True = masked (swm:1004)
         o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=allowed)
         return a.out_proj(o.transpose(1, 2).reshape(B, L, D))
@@ -361,6 +386,7 @@ class BlockCausalMask:
         whole = (seq_len // tokens_per_timestep) * tokens_per_timestep
         if whole < seq_len:                       # rows of a trailing partial timestep stay fully masked
             mask[whole:, :] = True
+        mask.tokens_per_timestep = tokens_per_timestep      # lets the attention pick its block-causal mode
         return mask
 
 
@@ -433,6 +459,8 @@ class AutoregressivePredictor(nn.Module):
                 grown = torch.ones(new, new, dtype=torch.bool, device=x.device)
                 grown[:old, :old] = attn_mask
                 grown[old:, :new] = False
+                if hasattr(attn_mask, "tokens_per_timestep"):     # one more whole timestep: still block-causal
+                    grown.tokens_per_timestep = attn_mask.tokens_per_timestep
                 attn_mask = grown
             seq = torch.cat([seq, step], dim=1)
             if predictor_blocks is not None:
