@@ -37,14 +37,21 @@ __global__ __launch_bounds__(HD) void gated_delta_kernel(const float* __restrict
     const float* vb = V + (int64_t)b * L * row_stride + h * HD;
     const float* ab_src[2] = {ALPHA + (int64_t)b * L * H + h, BETA + (int64_t)b * L * H + h};
 
-    float S[HD];
+    // row i of the state as float pairs: the step arithmetic is written on pairs so that it maps to packed
+    // f32 instructions on adjacent registers
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    f32x2_t S[HD / 2];
     if (STATE_IN != nullptr) {
         const float* src = STATE_IN + ((int64_t)bh * HD + i) * HD;
 #pragma unroll
-        for (int j = 0; j < HD; j += 4) *(f32x4_t*)(S + j) = *(const f32x4_t*)(src + j);
+        for (int j = 0; j < HD; j += 4) {
+            const f32x4_t v4 = *(const f32x4_t*)(src + j);
+            S[j / 2] = (f32x2_t){v4[0], v4[1]};
+            S[j / 2 + 1] = (f32x2_t){v4[2], v4[3]};
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < HD; ++j) S[j] = 0.f;
+        for (int j = 0; j < HD / 2; ++j) S[j] = (f32x2_t){0.f, 0.f};
     }
 
     const int r_in_pass = i * 4 / HD, col = (i * 4) % HD;     // this lane's 16 bytes inside a pass
@@ -78,32 +85,35 @@ __global__ __launch_bounds__(HD) void gated_delta_kernel(const float* __restrict
         for (int t = 0; t < steps; ++t) {
             const float a = ab[buf][0][t], bt = ab[buf][1][t];
             const float vi = vs[buf][t][i];
-            float kk[HD];
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x2_t kk[HD / 2];
+            f32x2_t acc[2] = {(f32x2_t){0.f, 0.f}, (f32x2_t){0.f, 0.f}};
 #pragma unroll
             for (int j = 0; j < HD; j += 4) {
-                *(f32x4_t*)(kk + j) = *(const f32x4_t*)&ks[buf][t][j];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(S[j + e], kk[j + e], acc[e]);
+                const f32x4_t k4 = *(const f32x4_t*)&ks[buf][t][j];
+                kk[j / 2] = (f32x2_t){k4[0], k4[1]};
+                kk[j / 2 + 1] = (f32x2_t){k4[2], k4[3]};
+                acc[0] = S[j / 2] * kk[j / 2] + acc[0];
+                acc[1] = S[j / 2 + 1] * kk[j / 2 + 1] + acc[1];
             }
-            const float sk = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            const float sk = (acc[0][0] + acc[0][1]) + (acc[1][0] + acc[1][1]);
             const float cu = bt * (vi - a * sk);
-            float oc[4] = {0.f, 0.f, 0.f, 0.f};
+            const f32x2_t cu2 = {cu, cu}, a2 = {a, a};
+            f32x2_t oc[2] = {(f32x2_t){0.f, 0.f}, (f32x2_t){0.f, 0.f}};
 #pragma unroll
             for (int j = 0; j < HD; j += 4) {
                 const f32x4_t q4 = *(const f32x4_t*)&qs[buf][t][j];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    S[j + e] = fmaf(cu, kk[j + e], a * S[j + e]);
-                    oc[e] = fmaf(S[j + e], q4[e], oc[e]);
-                }
+                S[j / 2] = cu2 * kk[j / 2] + a2 * S[j / 2];
+                S[j / 2 + 1] = cu2 * kk[j / 2 + 1] + a2 * S[j / 2 + 1];
+                oc[0] = S[j / 2] * (f32x2_t){q4[0], q4[1]} + oc[0];
+                oc[1] = S[j / 2 + 1] * (f32x2_t){q4[2], q4[3]} + oc[1];
             }
-            OUT[((int64_t)b * L + c * GD_T + t) * row_stride + h * HD + i] = (oc[0] + oc[1]) + (oc[2] + oc[3]);
+            OUT[((int64_t)b * L + c * GD_T + t) * row_stride + h * HD + i] = (oc[0][0] + oc[0][1]) + (oc[1][0] + oc[1][1]);
         }
     }
     float* dst = STATE_OUT + ((int64_t)bh * HD + i) * HD;
 #pragma unroll
-    for (int j = 0; j < HD; j += 4) *(f32x4_t*)(dst + j) = *(const f32x4_t*)(S + j);
+    for (int j = 0; j < HD; j += 4)
+        *(f32x4_t*)(dst + j) = (f32x4_t){S[j / 2][0], S[j / 2][1], S[j / 2 + 1][0], S[j / 2 + 1][1]};
 }
 
 // One wave per (batch, time) row of C channels; lane owns channels 4*lane + 256*m.

@@ -1,0 +1,87 @@
+"""Inference launch schedule of one predictor block (HybridPredictorBlock.forward, swm:975-997) on the HIP
+kernels: LayerNorm -> in-proj GEMM (+bias) -> block-causal attention -> out-proj GEMM (+bias +residual) ->
+[gated delta memory: projection GEMMs, causal conv + SiLU (+normalise), delta-rule recurrence, gating,
+LayerNorm, o-proj GEMM (+residual)] -> LayerNorm -> fc1 (+bias, GELU) -> fc2 (+bias +residual).
+
+Same numeric scheme as the encoder: f32 residual stream and statistics, bf16 GEMM/attention operands with f32
+accumulation.  The two 8-wide gate projections (a_proj, b_proj) and the elementwise gating stay torch ops.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .encoder_engine import WeightCache
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def block_supported(blk, x: torch.Tensor) -> bool:
+    D = x.shape[-1]
+    H = blk.spatial_attn.num_heads
+    return (D % 128 == 0 and D // H in (64, 128) and blk.spatial_attn.in_proj_bias is not None
+            and blk.spatial_attn._qkv_same_embed_dim)
+
+
+def block_forward(blk, x: torch.Tensor, tokens_per_timestep: int, state: Optional[torch.Tensor],
+                  wc: WeightCache) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """x f32 [B, L, D] on the device; tokens_per_timestep 0 = no mask.  Returns (x_out [B,L,D], new state)."""
+    B, L, D = x.shape
+    M = B * L
+    dev = x.device
+    a = blk.spatial_attn
+    H = a.num_heads
+    x2 = x.detach().reshape(M, D).contiguous()
+
+    def new(cols, dtype):
+        return torch.empty(M, cols, dtype=dtype, device=dev)
+
+    mean, rstd = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
+    ln = new(D, BF16)
+    ops.layernorm_fwd(x2, blk.norm1.weight, blk.norm1.bias, ln, mean, rstd, blk.norm1.eps)
+    qkv = new(3 * D, BF16)
+    ops.gemm_nt(ln, wc.fwd("in_proj", a.in_proj_weight), ops.EPI_BF16, qkv, bias=a.in_proj_bias.detach())
+    attn = new(D, BF16)
+    lse2 = torch.empty(B * H, L, dtype=F32, device=dev)
+    ops.attn_fwd(qkv, B, L, H, attn, lse2, tokens_per_timestep=tokens_per_timestep)
+    del qkv
+    x_mid = new(D, F32)
+    ops.gemm_nt(attn, wc.fwd("out_proj", a.out_proj.weight), ops.EPI_F32, x_mid, bias=a.out_proj.bias.detach(), resid=x2)
+
+    new_state = state
+    if blk.use_deltanet:
+        t = blk.temporal_layer
+        Hd, Dh = t.num_heads, t.head_dim
+        inner = Hd * Dh
+        xb = ops.cast_bf16(x_mid)
+        lin = {}
+        for name, cols in (("q", inner), ("k", inner), ("v", 2 * inner), ("g", inner)):
+            lin[name] = new(cols, F32)
+            ops.gemm_nt(xb, wc.fwd(name + "_proj", getattr(t, name + "_proj").weight), ops.EPI_F32, lin[name])
+        alpha = torch.sigmoid(x_mid @ t.a_proj.weight.detach().t()).view(B, L, Hd)
+        beta = torch.sigmoid(x_mid @ t.b_proj.weight.detach().t()).view(B, L, Hd)
+        q = ops.dwconv1d_causal_silu(lin["q"].view(B, L, inner), t.q_conv1d.weight.detach(), t.q_conv1d.bias.detach(), True)
+        k = ops.dwconv1d_causal_silu(lin["k"].view(B, L, inner), t.k_conv1d.weight.detach(), t.k_conv1d.bias.detach(), True)
+        v = ops.dwconv1d_causal_silu(lin["v"].view(B, L, 2 * inner), t.v_conv1d.weight.detach(), t.v_conv1d.bias.detach(), False)
+        v, v_gate = v[..., :inner].contiguous(), v[..., inner:]
+        out, new_state = ops.gated_delta_seq(q.view(B, L, Hd, Dh), k.view(B, L, Hd, Dh), v.view(B, L, Hd, Dh),
+                                             alpha.contiguous(), beta.contiguous(),
+                                             None if state is None else state.detach().contiguous())
+        gated = (out.view(B, L, inner) * v_gate * F.silu(lin["g"].view(B, L, inner))).reshape(M, inner)
+        del lin, q, k, v, out
+        on = new(inner, BF16)
+        ops.layernorm_fwd(gated, t.o_norm.weight, t.o_norm.bias, on, mean, rstd, t.o_norm.eps)
+        x_dn = new(D, F32)
+        ops.gemm_nt(on, wc.fwd("o_proj", t.o_proj.weight), ops.EPI_F32, x_dn, resid=x_mid)
+        x_mid = x_dn
+
+    ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, ln, mean, rstd, blk.norm2.eps)
+    pre, act = new(4 * D, BF16), new(4 * D, BF16)
+    ops.gemm_nt(ln, wc.fwd("fc1", blk.mlp[0].weight), ops.EPI_BIAS_GELU, pre, out2=act, bias=blk.mlp[0].bias.detach())
+    del pre
+    x_out = new(D, F32)
+    ops.gemm_nt(act, wc.fwd("fc2", blk.mlp[2].weight), ops.EPI_F32, x_out, bias=blk.mlp[2].bias.detach(), resid=x_mid)
+    return x_out.view(B, L, D), new_state

@@ -20,9 +20,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, predictor_engine
 from ._lib import VitAmdError
-from .encoder_engine import EncoderConfig, EncoderEngine, encoder_param_names
+from .encoder_engine import EncoderConfig, EncoderEngine, WeightCache, encoder_param_names
 
 _ROPE_SPLIT = {"t_dim": 256, "h_dim": 384, "w_dim": 384}          # swm:731-735
 
@@ -369,6 +369,12 @@ class HybridPredictorBlock(nn.Module):
         return a.out_proj(o.transpose(1, 2).reshape(B, L, D))
 
     def forward(self, x, attn_mask=None, state=None):
+        tpt = 0 if attn_mask is None else getattr(attn_mask, "tokens_per_timestep", -1)
+        if (_hip_inference(x) and tpt >= 0 and (tpt == 0 or x.shape[1] % tpt == 0)
+                and predictor_engine.block_supported(self, x)):
+            if getattr(self, "_operand_cache", None) is None:
+                self._operand_cache = WeightCache()
+            return predictor_engine.block_forward(self, x, tpt, state, self._operand_cache)
         x = x + self._masked_attention(self.norm1(x), attn_mask)
         if self.use_deltanet:
             delta, state = self.temporal_layer(x, state)
