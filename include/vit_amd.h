@@ -149,6 +149,33 @@ int va_gated_delta_seq(const float* q, const float* k, const float* v, const flo
 int va_dwconv1d_causal_silu(const float* x, const float* w, const float* bias, float* out, int64_t B, int64_t L,
                             int64_t C, int normalize, va_stream_t stream);
 
+/* ---- optimizer step of the training loops (stage1_surgvu_pretraining.py:390 AdamW, :469
+ * clip_grad_norm_(max_norm=1.0), :470 optimizer.step()) as multi-tensor kernels ----------------------------
+ * A parameter set is a DEVICE array of va_opt_tensor records, f32 pointers with n elements each, plus a DEVICE table of
+ * int32 pairs (tensor index, chunk index), one pair per VA_OPT_CHUNK elements of every tensor. */
+#define VA_OPT_CHUNK 65536
+typedef struct {
+    float* p;        /* parameter                 */
+    const float* g;  /* gradient                  */
+    float* m;        /* first moment  (exp_avg)   */
+    float* v;        /* second moment (exp_avg_sq)*/
+    int64_t n;
+    float inv_bc1;       /* 1 / (1 - beta1^step) of THIS tensor (torch counts steps per parameter) */
+    float inv_sqrt_bc2;  /* 1 / sqrt(1 - beta2^step)                                                */
+} va_opt_tensor;
+/* total[0] = sum over all tensors of g^2 (the squared global L2 norm); partial: workspace of num_chunks
+ * floats.  Fixed summation order (bitwise reproducible). */
+int va_multi_sumsq(const va_opt_tensor* tensors, const int32_t* chunk_table, int64_t num_chunks, float* partial,
+                   float* total, va_stream_t stream);
+/* One AdamW step (torch.optim.AdamW arithmetic, decoupled weight decay, bias corrections from the tensor
+ * records).  If
+ * total_sumsq is non-NULL and max_norm > 0 the gradients are first scaled by
+ * min(1, max_norm / (sqrt(total_sumsq[0]) + 1e-6)) as clip_grad_norm_ does; the gradient buffers themselves
+ * are left unscaled. */
+int va_multi_adamw(const va_opt_tensor* tensors, const int32_t* chunk_table, int64_t num_chunks, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, const float* total_sumsq, float max_norm,
+                   va_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
