@@ -149,6 +149,13 @@ int va_gated_delta_seq(const float* q, const float* k, const float* v, const flo
 int va_dwconv1d_causal_silu(const float* x, const float* w, const float* bias, float* out, int64_t B, int64_t L,
                             int64_t C, int normalize, va_stream_t stream);
 
+/* ---- input pipeline: the tensor side of the reference's per-frame transform (ToTensor + Normalize,
+ * stage1_surgvu_pretraining.py:241-244, 279-286) ---------------------------------------------------------
+ * frames: uint8 [B, T, H, W, 3] on the device -> out: f32 [B, 3, T, H, W], (u / 255 - mean[c]) / std[c]
+ * (bit-identical to the torch f32 arithmetic).  mean3 / std3: three HOST floats each.  H*W % 4 == 0. */
+int va_normalize_u8(const uint8_t* frames, float* out, int64_t B, int64_t T, int64_t H, int64_t W, const float* mean3,
+                    const float* std3, va_stream_t stream);
+
 /* ---- optimizer step of the training loops (stage1_surgvu_pretraining.py:390 AdamW, :469
  * clip_grad_norm_(max_norm=1.0), :470 optimizer.step()) as multi-tensor kernels ----------------------------
  * A parameter set is a DEVICE array of va_opt_tensor records, f32 pointers with n elements each, plus a DEVICE table of

@@ -445,3 +445,12 @@ def hybrid_predictor_block(x, P: Dict[str, torch.Tensor], prefix: str, heads: in
     h = layer_norm(x, P[prefix + "norm2.weight"], P[prefix + "norm2.bias"])
     h = gelu_erf(h @ P[prefix + "mlp.0.weight"].t() + P[prefix + "mlp.0.bias"])
     return x + h @ P[prefix + "mlp.2.weight"].t() + P[prefix + "mlp.2.bias"], state
+
+
+def normalize_u8(frames: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
+    """ToTensor + Normalize of the reference's clip transform (stage1_surgvu_pretraining.py:241-244, 279-286) on a
+    stack of frames: uint8 (B,T,H,W,3) -> f32 (B,3,T,H,W) = (u/255 - mean)/std."""
+    x = frames.permute(0, 4, 1, 2, 3).to(torch.float32).div(255)
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1, 1)
+    return (x - m) / s

@@ -314,3 +314,14 @@ def test_ema_and_l1(ops, dev):
         rl, rg = R.l1_latent_loss(p.float().cpu(), t.float().cpu())
         assert abs(loss.item() - rl.item()) < 1e-5 * max(1.0, rl.item())
         assert torch.equal(grad.float().cpu(), rg.to(dtype).float())
+
+
+# ------------------------------------------------------------------------------ input pipeline
+@pytest.mark.parametrize("B,T,H,W", [(1, 1, 2, 2), (2, 4, 32, 32), (1, 3, 18, 22)])
+def test_normalize_u8_bit_exact(ops, dev, B, T, H, W):
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (B, T, H, W, 3), generator=g, dtype=torch.uint8)
+    frames[0, 0, 0, 0] = torch.tensor([0, 255, 128], dtype=torch.uint8)
+    out = ops.normalize_u8(frames.to(dev))
+    assert torch.equal(out.cpu(), R.normalize_u8(frames))

@@ -43,6 +43,7 @@ SIGNATURES = {
     "va_token_scatter": (ci, [vp, vp, vp, i64, i64, i64, i64, vp]),
     "va_ema_update": (ci, [vp, vp, vp, i64, cf, vp]),
     "va_l1_loss": (ci, [vp, vp, ci, vp, vp, ci, cf, i64, vp]),
+    "va_normalize_u8": (ci, [vp, vp, i64, i64, i64, i64, vp, vp, vp]),
     "va_multi_sumsq": (ci, [vp, vp, i64, vp, vp, vp]),
     "va_multi_adamw": (ci, [vp, vp, i64, cf, cf, cf, cf, cf, vp, cf, vp]),
     "va_gated_delta_seq": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),

@@ -402,6 +402,35 @@ __global__ __launch_bounds__(256) void l1_kernel(const void* __restrict__ pred, 
 
 inline unsigned blocks_for(int64_t items, int per_block) { return (unsigned)((items + per_block - 1) / per_block); }
 
+// uint8 frames [B, T, H, W, 3] -> f32 clip [B, 3, T, H, W], (u / 255 - mean[c]) / std[c] with the same three
+// f32 operations, in the same order, as ToTensor + Normalize (stage1_surgvu_pretraining.py:241-244, 279-281).
+// A thread converts 4 neighbouring pixels (12 bytes in, three 16-byte stores out); HW % 4 == 0.
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                           int64_t quads, int64_t frame_px, int64_t T, f32x4_t mean,
+                                                           f32x4_t stdv) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;     // quad index over (b, t, pixel/4)
+    if (q >= quads) return;
+    const int64_t px = q * 4;
+    const int64_t bt = px / frame_px, off = px % frame_px;
+    const int64_t b = bt / T, t = bt % T;
+    const uint32_t* src = (const uint32_t*)(in + px * 3);
+    const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+    uint8_t u[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u[i] = (w0 >> (8 * i)) & 0xff;
+        u[4 + i] = (w1 >> (8 * i)) & 0xff;
+        u[8 + i] = (w2 >> (8 * i)) & 0xff;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x4_t v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ((float)u[3 * i + c] / 255.0f - mean[c]) / stdv[c];
+        *(f32x4_t*)(out + ((b * 3 + c) * T + t) * frame_px + off) = v;
+    }
+}
+
 }  // namespace
 
 // ===================================================================================================
@@ -572,5 +601,20 @@ extern "C" int va_l1_loss(const void* pred, const void* target, int in_bf16, flo
     else { if (grad_bf16) VA_L1(false, true); else VA_L1(false, false); }
 #undef VA_L1
     VA_CHECK_LAUNCH("va_l1_loss");
+    return VA_OK;
+}
+
+extern "C" int va_normalize_u8(const uint8_t* frames, float* out, int64_t B, int64_t T, int64_t H, int64_t W,
+                               const float* mean3, const float* std3, hipStream_t stream) {
+    VA_CHECK_ARG(frames && out && mean3 && std3, "va_normalize_u8: null operand");
+    VA_CHECK_ARG(B > 0 && T > 0 && H > 0 && W > 0 && (H * W) % 4 == 0, "va_normalize_u8: H*W must be a positive multiple of 4");
+    VA_CHECK_ARG((uintptr_t)frames % 4 == 0 && (uintptr_t)out % 16 == 0, "va_normalize_u8: misaligned operand");
+    VA_CHECK_ARG(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "va_normalize_u8: zero std");
+    const int64_t quads = B * T * H * W / 4;
+    VA_CHECK_ARG(quads < (1ll << 39), "va_normalize_u8: problem too large");
+    const f32x4_t mean = {mean3[0], mean3[1], mean3[2], 0.f}, stdv = {std3[0], std3[1], std3[2], 1.f};
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, frames, out, quads,
+                       H * W, T, mean, stdv);
+    VA_CHECK_LAUNCH("va_normalize_u8");
     return VA_OK;
 }

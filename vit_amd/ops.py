@@ -268,6 +268,27 @@ def cast_transpose_bf16(w: torch.Tensor, dst: Optional[torch.Tensor] = None) -> 
     return dst
 
 
+# ------------------------------------------------------------------ input pipeline
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def normalize_u8(frames: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+    """uint8 frames (B,T,H,W,3) on the device -> f32 clip (B,3,T,H,W), (u/255 - mean)/std."""
+    if frames.dtype != torch.uint8 or frames.dim() != 5 or frames.shape[-1] != 3 or not frames.is_contiguous():
+        raise ValueError("normalize_u8: frames must be contiguous uint8 (B,T,H,W,3)")
+    if not frames.is_cuda:
+        raise _lib.VitAmdError("normalize_u8: tensor must live on a HIP device")
+    B, T, H, W, _ = frames.shape
+    out = torch.empty(B, 3, T, H, W, dtype=F32, device=frames.device)
+    import ctypes
+    m3 = (ctypes.c_float * 3)(*mean)
+    s3 = (ctypes.c_float * 3)(*std)
+    check(_lib.load().va_normalize_u8(_p(frames), _p(out), B, T, H, W, ctypes.addressof(m3), ctypes.addressof(s3),
+                                      _stream()), "va_normalize_u8")
+    return out
+
+
 # ------------------------------------------------------------------ masking / JEPA pieces
 def future_mask(x: torch.Tensor, first_masked_row: int):
     if x.dim() != 3 or not x.is_contiguous() or x.dtype not in (BF16, F32):
