@@ -6,7 +6,7 @@
 // All three kernels share one skeleton (gfx950, wave64, MFMA 32x32x16 bf16):
 //   * a workgroup is 4 waves; each wave owns 32 "stationary" rows (queries in forward / dQ, keys in
 //     dK/dV) whose operand fragments stay in registers; the other side streams through LDS in tiles of
-//     64 rows, double-buffered with 16-byte direct-to-LDS loads, one barrier per tile.
+//     64 rows (a ring of two or three slots, 16-byte direct-to-LDS loads, one barrier per tile).
 //   * scores are produced with the streamed side as the MFMA A operand, so a lane holds a COLUMN of the
 //     score tile (one stationary row) and softmax statistics are per-lane scalars (one cross-half
 //     exchange per reduction).  The accumulator tile then feeds the next MFMA directly as its B operand
@@ -15,6 +15,9 @@
 //   * one LDS image serves both the row reads (ds_read_b128) and the transposed reads: 16-byte chunk
 //     index XOR f(row), f chosen so both patterns hit all 64 banks (see swz()).
 //   * dQ and dK/dV are separate passes (scores recomputed in each): no atomics, bitwise reproducible.
+//   * the softmax bookkeeping is kept off the VALU, which is the co-limiting pipe at head dim 64: scale
+//     folded into the stationary operand, running max / log-sum-exp / delta entering as accumulator start
+//     values or through one extra MFMA slice (see the kernels).
 #include "common.h"
 #include <type_traits>
 

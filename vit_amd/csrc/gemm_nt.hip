@@ -10,15 +10,17 @@
 //     per-lane SOURCE address (XOR on the 16-byte chunk index) and applying the same XOR when reading.
 //   * each wave owns a (BM/WM) x (BN/WN) sub-tile as 16x16x32 bf16 MFMAs.  The weight tile is the MFMA
 //     A operand and the activation tile the B operand, so an accumulator lane holds 4 consecutive
-//     output columns of one output row: stores are 8-byte (bf16) / 16-byte (f32) vectors.
+//     output columns of one output row.
 //   * launch-order block ids are remapped so that the blocks sharing an XCD walk neighbouring tiles.
 //
 // Two main loops:
-//   ring  (256x256 tile, 8 waves): K advances in 32-wide stages through a 4-slot LDS ring (4 x 32 KiB);
-//         loads run three stages ahead and are retired with COUNTED s_waitcnt vmcnt(N) in front of a raw
-//         s_barrier, so a stage stays in flight across every barrier.  MFMA fragments are read from LDS
-//         one stage ahead of their use, interleaved with the MFMAs of the current stage, so the LDS pipe
-//         and the matrix pipe overlap.  One barrier per 32 MFMAs per wave.
+//   ring  (256x256 tile, 8 waves): K advances in 32-wide stages through a 5-slot LDS ring (5 x 32 KiB, the
+//         whole LDS of a CU).  Default form ("paired"): loads are issued for two stages at a time so that
+//         both 64-byte halves of every 128-byte line are requested back to back, one pair in flight while
+//         two stages compute, counted s_waitcnt + raw s_barrier every two stages.  Alternative form: one
+//         stage per barrier, three stages in flight.  MFMA fragments are read from LDS one stage ahead of
+//         their use, interleaved with the MFMAs of the current stage, so the LDS pipe and the matrix pipe
+//         overlap.  The epilogue writes 64 contiguous bytes per output row and store instruction.
 //   pair  (128x128 tile, 4 waves; also selectable at 256x256): K advances in 64-wide tiles through two
 //         buffers, next tile issued before the current tile's MFMAs, vmcnt(0) + barrier per tile.  Used
 //         for small M and short K.

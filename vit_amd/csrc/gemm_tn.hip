@@ -1,20 +1,25 @@
 // Weight-gradient GEMM:  dW[N,K] (f32) += dY[M,N]^T * X[M,K],  bf16 operands, contraction over the
 // token dimension M (tens of thousands), which is the SLOW index of both operands in memory.
 //
-// Structure (gfx950):
-//   * workgroup tile 128(n) x 128(k), contraction step 64 rows of M, 4 waves (2x2), each wave a 64x64
-//     sub-tile as 2x2 MFMA 32x32x16 tiles.
-//   * both operand tiles are staged exactly as they lie in memory ([64 m][128 cols], 256-byte rows) with
-//     16-byte direct-to-LDS loads; the MFMA fragments (8 consecutive m for one column) are produced by
-//     the hardware transposing LDS read ds_read_b64_tr_b16, two per fragment.  The 16-byte chunk index
-//     is XORed with ((row&3)<<2) on the load's source address and on the read, which spreads the four
-//     rows of one transposed read over all 64 banks.
-//   * M is split over gridDim.y slices; every slice adds its tile into dW with f32 atomics.  dY^T is
-//     the MFMA A operand, so one accumulator register across a wave is two 128-byte row segments of dW,
-//     the shape at which the memory-side atomic units run at full rate.
+// Common structure (gfx950):
+//   * both operand tiles are staged exactly as they lie in memory ([rows of m][columns]) with 16-byte
+//     direct-to-LDS loads; the MFMA fragments (8 consecutive m for one column) are produced by the hardware
+//     transposing LDS read ds_read_b64_tr_b16, two per fragment.  The 16-byte chunk index is XORed with
+//     ((row&3)<<2) on the load's source address and on the read, which spreads the four rows of one
+//     transposed read over all 64 banks.
+//   * M is split into slices; every slice adds its tile into dW with f32 atomics.  dY^T is the MFMA A
+//     operand, so one accumulator register across a wave is two 128-byte row segments of dW, the shape at
+//     which the memory-side atomic units run at full rate.
 //   * a ragged last M-tile is zero-filled in LDS after it lands (sources are clamped to row M-1).
-//   * the bias gradient (column sums of dY) is optionally fused: one extra MFMA against an all-ones
-//     operand reuses the dY^T fragments that are in registers anyway, instead of a second pass over dY.
+//   * the bias gradient (column sums of dY) is optionally fused: MFMAs against an all-ones operand reuse
+//     the dY^T fragments that are in registers anyway, instead of a second pass over dY.
+//
+// Two kernels:
+//   gemm_tn_ring_kernel  256(n) x 256(k) tile, 8 waves, 32 rows of M per stage through a 5-slot LDS ring with
+//                        counted waits (as the forward GEMM's ring), fragments double-buffered in registers,
+//                        slices and tiles laid out over XCD-aware work ids; the default for large problems.
+//   gemm_tn_kernel       128 x 128 tile, 4 waves (2x2 of 64x64, MFMA 32x32x16), 64 rows of M per step through two
+//                        buffers; small shapes, and shapes the ring kernel's constraints exclude.
 #include "common.h"
 #include <type_traits>
 
