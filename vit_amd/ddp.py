@@ -24,10 +24,13 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
 class BucketReducer:
     """Averages flat gradient buckets across ranks, overlapping with whatever the caller enqueues next."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
+        """always_reduce: issue the collectives even in a world of one (exercises the stream hand-over on a
+        single GPU; the result is unchanged)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
+        self.always_reduce = always_reduce
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self._comm_stream: Optional[torch.cuda.Stream] = None
@@ -37,7 +40,7 @@ class BucketReducer:
 
     def submit(self, flat: torch.Tensor) -> None:
         """Start the all-reduce of one bucket; its producer kernels are already on the current stream."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_reduce:
             return
         native_avg = self.backend == "nccl"
         op = dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM

@@ -74,14 +74,18 @@ def stage1_losses(model, heads: Stage1Heads, video, video_aug, shuffled_video, o
     return total, (l_t.detach(), l_c.detach(), l_m.detach())
 
 
-def stage1_step(model, heads: Stage1Heads, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor],
-                max_norm: float = 1.0, **kw) -> Tuple[float, Tuple[torch.Tensor, ...]]:
+def stage1_step(model, heads: Stage1Heads, optimizer, batch: Dict[str, torch.Tensor],
+                max_norm: Optional[float] = 1.0, **kw) -> Tuple[float, Tuple[torch.Tensor, ...]]:
+    """One optimisation step (s1:418-470).  `optimizer` is a torch optimizer (then the gradients are clipped here
+    with clip_grad_norm_) or a `vit_amd.optim.FusedAdamW` built with `max_grad_norm` (clipping happens inside its
+    update kernel: pass max_norm=None)."""
     optimizer.zero_grad(set_to_none=True)
     loss, parts = stage1_losses(model, heads, batch["video"], batch["video_augmented"], batch["shuffled_video"],
                                 batch["order_label"].long(), **kw)
     loss.backward()
-    params = [p for g in optimizer.param_groups for p in g["params"]]
-    torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+    if max_norm is not None:
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
     optimizer.step()
     return float(loss.detach()), parts
 
