@@ -101,8 +101,9 @@ int va_attn_fwd_block_causal(const void* q, const void* k, const void* v, void* 
                              int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t tokens_per_timestep,
                              va_stream_t stream);
 /* backward of the same: given o, do (bf16, layout of o), lse2, writes dq, dk, dv (layout of q/k/v, ld =
- * lddqkv).  workspace: 5*B*H*N floats, 16-byte aligned (per-query softmax statistics in the two forms the
- * dQ and dK/dV passes consume). */
+ * lddqkv).  workspace: va_attn_bwd_workspace_bytes(B, N, H) bytes (5*B*H*N floats), 16-byte aligned (per-query
+ * softmax statistics in the two forms the dQ and dK/dV passes consume). */
+int64_t va_attn_bwd_workspace_bytes(int64_t B, int64_t N, int64_t H);
 int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2,
                 float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N, int64_t H, int64_t hd,
                 int64_t ldqkv, int64_t ldo, int64_t lddqkv, va_stream_t stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "va_rope3d_qk_inplace": (ci, [vp, vp, i64, i64, i64, i64, ci, vp]),
     "va_attn_fwd": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp]),
     "va_attn_fwd_block_causal": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
+    "va_attn_bwd_workspace_bytes": (i64, [i64, i64, i64]),
     "va_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
     "va_cast_f32_bf16": (ci, [vp, vp, i64, vp]),
     "va_cast_transpose_f32_bf16": (ci, [vp, vp, i64, i64, vp]),

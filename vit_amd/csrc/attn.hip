@@ -740,6 +740,10 @@ extern "C" int va_attn_fwd_block_causal(const void* q, const void* k, const void
                           stream);
 }
 
+extern "C" int64_t va_attn_bwd_workspace_bytes(int64_t B, int64_t N, int64_t H) {
+    return (B > 0 && N > 0 && H > 0) ? 5 * B * H * N * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                            const float* lse2, float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N,
                            int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t lddqkv, hipStream_t stream) {

@@ -205,7 +205,7 @@ def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int):
         raise ValueError("attn_bwd: inconsistent shapes")
     hd = D // H
     es = 2
-    delta = torch.empty(5 * B * H * N, dtype=F32, device=qkv.device)     # workspace
+    delta = torch.empty(_lib.load().va_attn_bwd_workspace_bytes(B, N, H) // 4, dtype=F32, device=qkv.device)   # workspace
     check(_lib.load().va_attn_bwd(qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out),
                                   _p(d_out), _p(lse2), _p(delta), dqkv.data_ptr(), dqkv.data_ptr() + D * es,
                                   dqkv.data_ptr() + 2 * D * es, B, N, H, hd, _ld(qkv), _ld(out), _ld(dqkv), _stream()),
