@@ -14,6 +14,7 @@ Reference citations: swm = surgical_world_model.py of HananKibria/VIT.
 from __future__ import annotations
 
 import math
+import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -167,6 +168,8 @@ class _EncoderFn(torch.autograd.Function):
 
 
 class VideoViTEncoder(nn.Module):
+    _warned_no_dropout = False
+
     """Tubelet embedding + 3-D RoPE transformer encoder (swm:717-817) on the MI355X engine."""
 
     def __init__(self, img_size=224, num_frames=16, tubelet_size=(2, 16, 16), in_channels=3, embed_dim=1024,
@@ -213,6 +216,11 @@ class VideoViTEncoder(nn.Module):
     def forward(self, video: torch.Tensor) -> torch.Tensor:
         if not video.is_cuda:
             raise VitAmdError("VideoViTEncoder.forward needs a HIP device tensor: vit_amd has no CPU fallback")
+        if self.training and not VideoViTEncoder._warned_no_dropout:
+            # the reference's blocks carry nn.Dropout(0.1) (swm:263, 700-702) that is active under model.train()
+            VideoViTEncoder._warned_no_dropout = True
+            warnings.warn("vit_amd.VideoViTEncoder computes the eval-mode arithmetic in training mode too: the "
+                          "p=0.1 dropouts inside the encoder blocks are not applied", stacklevel=2)
         named = dict(self.named_parameters())
         params = [named[n] for n in self._param_order]
         for n, p in zip(self._param_order, params):
