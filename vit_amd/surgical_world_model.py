@@ -168,9 +168,9 @@ class _EncoderFn(torch.autograd.Function):
 
 
 class VideoViTEncoder(nn.Module):
-    _warned_no_dropout = False
-
     """Tubelet embedding + 3-D RoPE transformer encoder (swm:717-817) on the MI355X engine."""
+
+    _warned_no_dropout = False
 
     def __init__(self, img_size=224, num_frames=16, tubelet_size=(2, 16, 16), in_channels=3, embed_dim=1024,
                  depth=12, num_heads=12, use_grad_checkpoint=False):
