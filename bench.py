@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="clips per GPU (the headline number uses 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-mode", action="store_true",
+                    help="model.train(): the blocks' p=0.1 dropouts are applied (the headline number is eval mode)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,6 +111,8 @@ def main():
 
     torch.manual_seed(42)
     enc = swm.VideoViTEncoder(img_size=IMG, num_frames=FRAMES, embed_dim=DIM, depth=DEPTH, num_heads=HEADS).eval().to(dev)
+    if args.train_mode:
+        enc.train()
     reducer = None
     if world > 1:
         for p in enc.parameters():                       # identical replicas
@@ -175,7 +179,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "ViT-L encoder (dim 1024, depth 24, heads 16) forward+backward, 16x256x256 clips, "
-                                   "tubelet 2x16x16 (2048 tokens/clip), eval-mode dropout, loss = mean(out^2)",
+                                   "tubelet 2x16x16 (2048 tokens/clip), "
+                                   + ("training-mode dropout p=0.1" if args.train_mode else "eval-mode dropout")
+                                   + ", loss = mean(out^2)",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "model_flops_utilization": round(value * flops_per_clip(n_tokens) / (world * PEAK_BF16_FLOPS), 4),

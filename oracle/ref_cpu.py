@@ -192,9 +192,61 @@ def gelu_erf(x):
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
+# --------------------------------------------------------------------------
+# training-mode dropout.  The reference draws its masks from torch's generator (nn.Dropout, swm:263, 700-702);
+# the library under test draws them from a counter-based hash documented in its header.  This is an independent
+# numpy restatement of that documented hash, so that a training-mode forward/backward can be compared on
+# IDENTICAL masks; the rest of the arithmetic (mask * x / (1 - p)) is the reference's.
+# --------------------------------------------------------------------------
+def drop_thresh16(p: float) -> int:
+    return int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+
+
+def drop_scale(p: float) -> float:
+    return float(np.float32(65536.0) / np.float32(65536 - drop_thresh16(p)))
+
+
+def _drop_mix(pair: np.ndarray, key: np.ndarray) -> np.ndarray:
+    M = np.uint64(0xFFFFFFFF)
+    x = (pair.astype(np.uint64) * np.uint64(0x9E3779B1) + key.astype(np.uint64)) & M
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x2C1B3C6D)) & M
+    x ^= x >> np.uint64(12)
+    x = (x * np.uint64(0x297A2D39)) & M
+    x ^= x >> np.uint64(15)
+    return x
+
+
+def drop_keep_elems(key, elem: np.ndarray, p: float) -> np.ndarray:
+    """Boolean keep decision of the elements with (uint32, wrapping) indices `elem` under `key` (scalar or array)."""
+    elem = np.asarray(elem, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    h = _drop_mix(elem >> np.uint64(1), np.asarray(key, dtype=np.uint64) & np.uint64(0xFFFFFFFF))
+    field = np.where((elem & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return field >= np.uint64(drop_thresh16(p))
+
+
+def drop_mask(key: int, shape, p: float) -> torch.Tensor:
+    """Multiplier tensor (0 or 1/(1-p)) of a contiguous tensor of `shape`: element index = flat index."""
+    n = int(np.prod(shape))
+    keep = drop_keep_elems(key, np.arange(n, dtype=np.uint64), p)
+    return torch.from_numpy(keep.astype(np.float32) * np.float32(drop_scale(p))).reshape(tuple(shape))
+
+
+def attn_drop_mask(key: int, B: int, H: int, N: int, p: float) -> torch.Tensor:
+    """Multiplier tensor [B, H, N, N] of the attention probabilities: head-batch bh = b*H + h uses the key
+    key + bh * 0x9E3779B9 and element index q * NS + k, NS = N rounded up to even."""
+    NS = (N + 1) & ~1
+    bh = np.arange(B * H, dtype=np.uint64)[:, None, None]
+    keys = (np.uint64(key) + bh * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    elem = (np.arange(N, dtype=np.uint64)[None, :, None] * np.uint64(NS) + np.arange(N, dtype=np.uint64)[None, None, :])
+    keep = drop_keep_elems(np.broadcast_to(keys, (B * H, N, N)), np.broadcast_to(elem, (B * H, N, N)), p)
+    return torch.from_numpy(keep.astype(np.float32) * np.float32(drop_scale(p))).reshape(B, H, N, N)
+
+
 def rope_attention(x, w_qkv, w_out, heads: int, grid: Optional[Tuple[int, int, int]],
-                   attn_mask: Optional[torch.Tensor] = None):
-    """swm:283-336 (eval mode: dropout is the identity).  w_qkv rows [0:D]=Q, [D:2D]=K, [2D:3D]=V."""
+                   attn_mask: Optional[torch.Tensor] = None, drop: Optional[torch.Tensor] = None):
+    """swm:283-336.  w_qkv rows [0:D]=Q, [D:2D]=K, [2D:3D]=V.  drop: multiplier [B,H,N,N] standing for
+    self.dropout(attn) in training mode (swm:326), None in eval mode."""
     B, N, D = x.shape
     hd = D // heads
     qkv = x @ w_qkv.t()
@@ -216,28 +268,40 @@ def rope_attention(x, w_qkv, w_out, heads: int, grid: Optional[Tuple[int, int, i
             m = m[:, None]
         s = s.masked_fill(m, float("-inf"))
     p = s.softmax(dim=-1)
+    if drop is not None:
+        p = p * drop
     o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, D)
     return o @ w_out.t()
 
 
-def vit_block(x, P: Dict[str, torch.Tensor], prefix: str, heads: int, grid, attn_mask=None):
-    """swm:705-714, eval mode."""
+def vit_block(x, P: Dict[str, torch.Tensor], prefix: str, heads: int, grid, attn_mask=None, drop=None):
+    """swm:705-714.  drop: None (eval mode) or ((p_attn, p_fc1, p_fc2), (key_attn, key_fc1, key_fc2))."""
     g = lambda k: P[prefix + k]
+    B, N, D = x.shape
+    (pa, p1, p2), (ka, k1, k2) = drop if drop is not None else ((0, 0, 0), (0, 0, 0))
     x = x + rope_attention(layer_norm(x, g("norm1.weight"), g("norm1.bias")),
-                           g("attn.qkv_proj.weight"), g("attn.out_proj.weight"), heads, grid, attn_mask)
+                           g("attn.qkv_proj.weight"), g("attn.out_proj.weight"), heads, grid, attn_mask,
+                           attn_drop_mask(ka, B, heads, N, pa) if pa > 0 else None)
     h = layer_norm(x, g("norm2.weight"), g("norm2.bias"))
     h = gelu_erf(h @ g("mlp.0.weight").t() + g("mlp.0.bias"))
-    return x + h @ g("mlp.3.weight").t() + g("mlp.3.bias")
+    if p1 > 0:
+        h = h * drop_mask(k1, h.shape, p1)
+    h = h @ g("mlp.3.weight").t() + g("mlp.3.bias")
+    if p2 > 0:
+        h = h * drop_mask(k2, h.shape, p2)
+    return x + h
 
 
 def encoder_forward(P: Dict[str, torch.Tensor], video: torch.Tensor, depth: int, heads: int,
-                    tubelet=(2, 16, 16)) -> torch.Tensor:
-    """swm:772-817, eval mode.  (B,C,T,H,W) -> (B, N, D)."""
+                    tubelet=(2, 16, 16), drop_p=None, drop_keys=None) -> torch.Tensor:
+    """swm:772-817.  (B,C,T,H,W) -> (B, N, D).  drop_p / drop_keys: per block three probabilities / keys
+    (training mode); None for eval mode."""
     B, C, T, H, W = video.shape
     grid = (T // tubelet[0], H // tubelet[1], W // tubelet[2])
     x = tubelet_embed(video, P["tubelet_embed.projection.weight"], P["tubelet_embed.projection.bias"], tubelet)
     for i in range(depth):
-        x = vit_block(x, P, f"blocks.{i}.", heads, grid)
+        x = vit_block(x, P, f"blocks.{i}.", heads, grid,
+                      drop=(drop_p[i], drop_keys[i]) if drop_p is not None else None)
     return layer_norm(x, P["norm.weight"], P["norm.bias"])
 
 

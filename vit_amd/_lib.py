@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint32, c_void_p
 
 # PyTorch-ROCm ships its own libamdhip64.so.7.  It must be the HIP runtime already resident when
 # libvit_amd.so is opened, so that the library's kernels launch into the runtime (and device context)
@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libvit_amd.so")
 
 _lib = None
 
-i64, vp, ci, cf = c_int64, c_void_p, c_int, c_float
+i64, vp, ci, cf, cu32 = c_int64, c_void_p, c_int, c_float, c_uint32
 
 # name -> (restype, argtypes); mirrors include/vit_amd.h one to one
 SIGNATURES = {
@@ -37,6 +37,10 @@ SIGNATURES = {
     "va_attn_fwd_block_causal": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
     "va_attn_bwd_workspace_bytes": (i64, [i64, i64, i64]),
     "va_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
+    "va_attn_fwd_dropout": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, cu32, cf, vp]),
+    "va_attn_bwd_dropout": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, cu32, cf,
+                                vp]),
+    "va_dropout": (ci, [vp, ci, vp, ci, vp, i64, cu32, cf, vp]),
     "va_cast_f32_bf16": (ci, [vp, vp, i64, vp]),
     "va_cast_transpose_f32_bf16": (ci, [vp, vp, i64, i64, vp]),
     "va_future_mask": (ci, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),

@@ -156,11 +156,19 @@ constexpr int fwd_ring_slots(int hd) { return hd == 64 ? 3 : 2; }
 // MODE: which keys a query sees.  0: all, N a multiple of 64.  1: all, ragged N.  2: block-causal, a query of
 // timestep s = n / tpt sees the keys of timesteps <= s (the predictor's mask, swm:1008-1028); N % tpt == 0.
 // Modes 1 and 2 are one mechanism: a per-lane key limit, applied only in tiles that reach past it.
-template <int HD, int MODE>
+// DROP: dropout on the attention probabilities (swm:326, training mode): the probabilities that enter P*V are
+// masked and rescaled, the softmax normaliser is not; element (q, k) of head bh takes its decision from
+// drop_hash(key + bh * 0x9E3779B9, (q * NS + k) / 2) with NS = N rounded up to even (32-bit wrap-around).
+struct DropArgs {
+    uint32_t key, thresh16;
+    float scale;
+};
+
+template <int HD, int MODE, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE2, int N, int H, int64_t ld, int64_t ldo,
-                                                       float c, int tpt) {
+                                                       float c, int tpt, DropArgs drop) {
     constexpr bool RAGGED = MODE != 0;
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
     constexpr int NBUF = fwd_ring_slots(HD), AHEAD = NBUF - 1, LOADS = 2 * TileSrc<HD>::PER_THREAD;
@@ -309,6 +317,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 st[kb][i] = p;
                 l += p;
             }
+        if (DROP) {
+            const uint32_t key = drop.key + (uint32_t)bh * 0x9E3779B9u;
+            const uint32_t base = (uint32_t)qrow_c * (((uint32_t)N + 1u) & ~1u) + (uint32_t)(t * TILE_ROWS);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {       // registers i, i+1 are keys k, k+1 with k even
+                    const uint32_t hsh = drop_hash(key, (base + kb * 32 + acc32_row(i, h)) >> 1);
+                    st[kb][i] = drop_keep(hsh, 0, drop.thresh16) ? st[kb][i] * drop.scale : 0.f;
+                    st[kb][i + 1] = drop_keep(hsh, 1, drop.thresh16) ? st[kb][i + 1] * drop.scale : 0.f;
+                }
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -392,13 +412,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------
 // dQ pass: query-stationary, streams K and V.
 // ------------------------------------------------------------------------------------------------
-template <int HD, bool RAGGED>
+template <int HD, bool RAGGED, bool DROP = false>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
                                                           const float* __restrict__ LSE2,
                                                           const float* __restrict__ DELTA, bf16_t* __restrict__ DQ,
                                                           int N, int H, int64_t ld, int64_t ldo, int64_t lddq, float c,
-                                                          float scale) {
+                                                          float scale, DropArgs drop) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -459,7 +479,14 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
                 vfr[ks] = row_frag<HD>(vt, kb * 32, ks, lane);
             }
             f32x16_t s = mfma32(kfr[0], qf[0], neg_lse);
-            f32x16_t dp = mfma32(vfr[0], dof[0], neg_dl);
+            f32x16_t dp;
+            if (DROP) {      // dP = mask * (dO V^T) - delta: delta cannot ride in the accumulator
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+                dp = mfma32(vfr[0], dof[0], dp);
+            } else {
+                dp = mfma32(vfr[0], dof[0], neg_dl);
+            }
 #pragma unroll
             for (int ks = 1; ks < KS; ++ks) {
                 s = mfma32(kfr[ks], qf[ks], s);
@@ -475,7 +502,19 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
             for (int i = 0; i < 16; ++i) {
                 float p = fast_exp2(s[i]);
                 if (ragged && t * TILE_ROWS + kb * 32 + acc32_row(i, h) >= N) p = 0.f;
-                s[i] = p * dp[i];
+                s[i] = DROP ? p : p * dp[i];
+            }
+            if (DROP) {
+                const uint32_t key = drop.key + (uint32_t)bh * 0x9E3779B9u;
+                const uint32_t base = (uint32_t)qrow_c * (((uint32_t)N + 1u) & ~1u) + (uint32_t)(t * TILE_ROWS + kb * 32);
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const uint32_t hsh = drop_hash(key, (base + acc32_row(i, h)) >> 1);
+                    const float m0 = drop_keep(hsh, 0, drop.thresh16) ? drop.scale : 0.f;
+                    const float m1 = drop_keep(hsh, 1, drop.thresh16) ? drop.scale : 0.f;
+                    s[i] *= fmaf(m0, dp[i], -dl);
+                    s[i + 1] *= fmaf(m1, dp[i + 1], -dl);
+                }
             }
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
@@ -502,12 +541,12 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
 template <int HD>
 constexpr int dkv_stage_bytes() { return 2 * TILE_ROWS * HD * 2 + TILE_ROWS * 16; }   // Q | dO | records
 
-template <int HD, bool RAGGED>
+template <int HD, bool RAGGED, bool DROP = false>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
                                                            const u32x4_t* __restrict__ AUX, bf16_t* __restrict__ DK,
                                                            bf16_t* __restrict__ DV, int N, int H, int64_t ld,
-                                                           int64_t ldo, int64_t lddq, float c, float scale) {
+                                                           int64_t ldo, int64_t lddq, float c, float scale, DropArgs drop) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
     constexpr int STAGE = dkv_stage_bytes<HD>();
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE] | 16 zero bytes
@@ -579,7 +618,14 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
             s = mfma32(__builtin_bit_cast(bf16x8_t, a_lse), ones, s);       // [query][key] = -lse2[query]
-            dp = mfma32(__builtin_bit_cast(bf16x8_t, a_dl), ones, dp);      //               -delta[query]
+            f32x16_t nd;                                                    // DROP: -delta kept apart from dP
+            if (DROP) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) nd[i] = 0.f;
+                nd = mfma32(__builtin_bit_cast(bf16x8_t, a_dl), ones, nd);
+            } else {
+                dp = mfma32(__builtin_bit_cast(bf16x8_t, a_dl), ones, dp);  //               -delta[query]
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s = mfma32(qfr[ks], kf[ks], s);
@@ -599,8 +645,17 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
             for (int i = 0; i < 16; ++i) {
                 float p = fast_exp2(s[i]);
                 if (ragged && t * TILE_ROWS + qb * 32 + acc32_row(i, h) >= N) p = 0.f;
-                pr[i] = p;
-                s[i] = p * dp[i];
+                if (DROP) {      // element (query, key = this lane's row): the pair's field is chosen by the key's parity
+                    const uint32_t qi = (uint32_t)(t * TILE_ROWS + qb * 32 + acc32_row(i, h));
+                    const uint32_t e = (qi < (uint32_t)N ? qi : (uint32_t)N - 1) * (((uint32_t)N + 1u) & ~1u) + (uint32_t)krow_c;
+                    const uint32_t hsh = drop_hash(drop.key + (uint32_t)bh * 0x9E3779B9u, e >> 1);
+                    const float mk = drop_keep(hsh, (int)(e & 1), drop.thresh16) ? drop.scale : 0.f;
+                    pr[i] = p * mk;
+                    s[i] = p * fmaf(mk, dp[i], nd[i]);
+                } else {
+                    pr[i] = p;
+                    s[i] = p * dp[i];
+                }
             }
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
@@ -647,42 +702,41 @@ int check_common(const char* who, int64_t B, int64_t N, int64_t H, int64_t hd, i
     return VA_OK;
 }
 
-template <int HD, int MODE>
+template <int HD, int MODE, bool DROP>
 int fwd_launch_mode(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
-                    int64_t ld, int64_t ldo, int tpt, hipStream_t stream) {
+                    int64_t ld, int64_t ldo, int tpt, DropArgs drop, hipStream_t stream) {
     constexpr int LDS = fwd_ring_slots(HD) * 2 * TILE_ROWS * HD * 2;
     static bool flags[64] = {};
     const float c = 1.4426950408889634f / sqrtf((float)HD);
     const dim3 grid((N + 127) / 128, B * H);
-    if (int e = set_lds(attn_fwd_kernel<HD, MODE>, LDS, flags, "va_attn_fwd")) return e;
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, MODE>), grid, dim3(256), LDS, stream, q, k, v, o, lse2, N, H, ld, ldo, c, tpt);
+    if (int e = set_lds(attn_fwd_kernel<HD, MODE, DROP>, LDS, flags, "va_attn_fwd")) return e;
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, MODE, DROP>), grid, dim3(256), LDS, stream, q, k, v, o, lse2, N, H, ld, ldo,
+                       c, tpt, drop);
     VA_CHECK_LAUNCH("va_attn_fwd");
     return VA_OK;
 }
 
 template <int HD>
 int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
-               int64_t ld, int64_t ldo, int tpt, hipStream_t stream) {
-    if (tpt > 0) return fwd_launch_mode<HD, 2>(q, k, v, o, lse2, B, N, H, ld, ldo, tpt, stream);
-    if (N % TILE_ROWS) return fwd_launch_mode<HD, 1>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, stream);
-    return fwd_launch_mode<HD, 0>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, stream);
+               int64_t ld, int64_t ldo, int tpt, DropArgs drop, hipStream_t stream) {
+    if (drop.thresh16) {   // training-mode dropout: the encoder's attention only (no key limit other than N)
+        if (N % TILE_ROWS) return fwd_launch_mode<HD, 1, true>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream);
+        return fwd_launch_mode<HD, 0, true>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream);
+    }
+    if (tpt > 0) return fwd_launch_mode<HD, 2, false>(q, k, v, o, lse2, B, N, H, ld, ldo, tpt, drop, stream);
+    if (N % TILE_ROWS) return fwd_launch_mode<HD, 1, false>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream);
+    return fwd_launch_mode<HD, 0, false>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream);
 }
 
-template <int HD>
-int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* d_o,
-               const float* lse2, float* workspace, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H, int64_t ld,
-               int64_t ldo, int64_t lddq, hipStream_t stream) {
+template <int HD, bool RAGGED, bool DROP>
+int bwd_launch_as(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* d_o,
+                  const float* lse2, float* workspace, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H,
+                  int64_t ld, int64_t ldo, int64_t lddq, DropArgs drop, hipStream_t stream) {
     constexpr int LDS_DQ = 2 * 2 * TILE_ROWS * HD * 2;
     constexpr int LDS_DKV = 2 * dkv_stage_bytes<HD>() + 16;
-    static bool f1[2][64] = {}, f2[2][64] = {};
-    const bool ragged = (N % TILE_ROWS) != 0;
-    if (ragged) {
-        if (int e = set_lds(attn_bwd_dq_kernel<HD, true>, LDS_DQ, f1[1], "va_attn_bwd")) return e;
-        if (int e = set_lds(attn_bwd_dkv_kernel<HD, true>, LDS_DKV, f2[1], "va_attn_bwd")) return e;
-    } else {
-        if (int e = set_lds(attn_bwd_dq_kernel<HD, false>, LDS_DQ, f1[0], "va_attn_bwd")) return e;
-        if (int e = set_lds(attn_bwd_dkv_kernel<HD, false>, LDS_DKV, f2[0], "va_attn_bwd")) return e;
-    }
+    static bool f1[64] = {}, f2[64] = {};
+    if (int e = set_lds(attn_bwd_dq_kernel<HD, RAGGED, DROP>, LDS_DQ, f1, "va_attn_bwd")) return e;
+    if (int e = set_lds(attn_bwd_dkv_kernel<HD, RAGGED, DROP>, LDS_DKV, f2, "va_attn_bwd")) return e;
     const float scale = 1.0f / sqrtf((float)HD);
     const float c = 1.4426950408889634f * scale;
     const int64_t rows = (int64_t)B * N;
@@ -694,40 +748,62 @@ int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* 
                        lse2, delta, aux, rows, N, H, ldo);
     VA_CHECK_LAUNCH("va_attn_bwd(delta)");
     const dim3 grid((N + 127) / 128, B * H);
-    if (ragged)
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), grid, dim3(256), LDS_DQ, stream, q, k, v, d_o, lse2, delta, dq,
-                           N, H, ld, ldo, lddq, c, scale);
-    else
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), grid, dim3(256), LDS_DQ, stream, q, k, v, d_o, lse2, delta, dq,
-                           N, H, ld, ldo, lddq, c, scale);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, RAGGED, DROP>), grid, dim3(256), LDS_DQ, stream, q, k, v, d_o, lse2,
+                       delta, dq, N, H, ld, ldo, lddq, c, scale, drop);
     VA_CHECK_LAUNCH("va_attn_bwd(dq)");
-    if (ragged)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux,
-                           dk, dv, N, H, ld, ldo, lddq, c, scale);
-    else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux,
-                           dk, dv, N, H, ld, ldo, lddq, c, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, RAGGED, DROP>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux, dk,
+                       dv, N, H, ld, ldo, lddq, c, scale, drop);
     VA_CHECK_LAUNCH("va_attn_bwd(dkv)");
     return VA_OK;
 }
 
+template <int HD>
+int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* d_o,
+               const float* lse2, float* workspace, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H, int64_t ld,
+               int64_t ldo, int64_t lddq, DropArgs drop, hipStream_t stream) {
+    const bool ragged = (N % TILE_ROWS) != 0;
+#define VA_BWD(R, D) bwd_launch_as<HD, R, D>(q, k, v, o, d_o, lse2, workspace, dq, dk, dv, B, N, H, ld, ldo, lddq, drop, stream)
+    if (drop.thresh16) return ragged ? VA_BWD(true, true) : VA_BWD(false, true);
+    return ragged ? VA_BWD(true, false) : VA_BWD(false, false);
+#undef VA_BWD
+}
+
 }  // namespace
 
+// p -> kernel arguments; p == 0 selects the kernels without any mask code
+static int make_drop(const char* who, uint32_t key, float p, DropArgs* out) {
+    VA_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout probability %g outside [0, 1)", who, (double)p);
+    out->key = key;
+    out->thresh16 = va_drop_thresh16(p);
+    VA_CHECK_ARG(out->thresh16 < 65536u, "%s: dropout probability %g rounds to 1", who, (double)p);
+    out->scale = va_drop_scale(out->thresh16);
+    return VA_OK;
+}
+
 static int attn_fwd_entry(const char* who, const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B,
-                          int64_t N, int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t tpt, hipStream_t stream) {
+                          int64_t N, int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t tpt, DropArgs drop,
+                          hipStream_t stream) {
     VA_CHECK_ARG(q && k && v && o && lse2, "%s: null operand", who);
     if (int e = check_common(who, B, N, H, hd, ldqkv, ldo)) return e;
     VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "%s: misaligned operand", who);
     if (hd == 64)
         return fwd_launch<64>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, (int)B, (int)N,
-                              (int)H, ldqkv, ldo, (int)tpt, stream);
+                              (int)H, ldqkv, ldo, (int)tpt, drop, stream);
     return fwd_launch<128>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, (int)B, (int)N, (int)H,
-                           ldqkv, ldo, (int)tpt, stream);
+                           ldqkv, ldo, (int)tpt, drop, stream);
 }
 
 extern "C" int va_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N,
                            int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, hipStream_t stream) {
-    return attn_fwd_entry("va_attn_fwd", q, k, v, o, lse2, B, N, H, hd, ldqkv, ldo, 0, stream);
+    return attn_fwd_entry("va_attn_fwd", q, k, v, o, lse2, B, N, H, hd, ldqkv, ldo, 0, DropArgs{0u, 0u, 1.f}, stream);
+}
+
+extern "C" int va_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B,
+                                   int64_t N, int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, uint32_t key, float p,
+                                   hipStream_t stream) {
+    DropArgs drop;
+    if (int e = make_drop("va_attn_fwd_dropout", key, p, &drop)) return e;
+    return attn_fwd_entry("va_attn_fwd_dropout", q, k, v, o, lse2, B, N, H, hd, ldqkv, ldo, 0, drop, stream);
 }
 
 extern "C" int va_attn_fwd_block_causal(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B,
@@ -737,28 +813,46 @@ extern "C" int va_attn_fwd_block_causal(const void* q, const void* k, const void
                  "va_attn_fwd_block_causal: N=%lld must be a whole number of timesteps of %lld tokens", (long long)N,
                  (long long)tokens_per_timestep);
     return attn_fwd_entry("va_attn_fwd_block_causal", q, k, v, o, lse2, B, N, H, hd, ldqkv, ldo, tokens_per_timestep,
-                          stream);
+                          DropArgs{0u, 0u, 1.f}, stream);
 }
 
 extern "C" int64_t va_attn_bwd_workspace_bytes(int64_t B, int64_t N, int64_t H) {
     return (B > 0 && N > 0 && H > 0) ? 5 * B * H * N * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                           const float* lse2, float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N,
-                           int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t lddqkv, hipStream_t stream) {
-    VA_CHECK_ARG(q && k && v && o && d_o && lse2 && workspace && dq && dk && dv, "va_attn_bwd: null operand");
-    VA_CHECK_ARG((uintptr_t)workspace % 16 == 0, "va_attn_bwd: workspace must be 16-byte aligned");
-    if (int e = check_common("va_attn_bwd", B, N, H, hd, ldqkv, ldo)) return e;
-    VA_CHECK_ARG(lddqkv >= H * hd && lddqkv % 8 == 0, "va_attn_bwd: bad gradient leading dimension");
+static int attn_bwd_entry(const char* who, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                          const float* lse2, float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N,
+                          int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t lddqkv, DropArgs drop,
+                          hipStream_t stream) {
+    VA_CHECK_ARG(q && k && v && o && d_o && lse2 && workspace && dq && dk && dv, "%s: null operand", who);
+    VA_CHECK_ARG((uintptr_t)workspace % 16 == 0, "%s: workspace must be 16-byte aligned", who);
+    if (int e = check_common(who, B, N, H, hd, ldqkv, ldo)) return e;
+    VA_CHECK_ARG(lddqkv >= H * hd && lddqkv % 8 == 0, "%s: bad gradient leading dimension", who);
     VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq |
                   (uintptr_t)dk | (uintptr_t)dv) % 16 == 0,
-                 "va_attn_bwd: misaligned operand");
+                 "%s: misaligned operand", who);
     if (hd == 64)
         return bwd_launch<64>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
                               lse2, workspace, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo,
-                              lddqkv, stream);
+                              lddqkv, drop, stream);
     return bwd_launch<128>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
                            lse2, workspace, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo, lddqkv,
-                           stream);
+                           drop, stream);
+}
+
+extern "C" int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                           const float* lse2, float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N,
+                           int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t lddqkv, hipStream_t stream) {
+    return attn_bwd_entry("va_attn_bwd", q, k, v, o, d_o, lse2, workspace, dq, dk, dv, B, N, H, hd, ldqkv, ldo, lddqkv,
+                          DropArgs{0u, 0u, 1.f}, stream);
+}
+
+extern "C" int va_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                   const float* lse2, float* workspace, void* dq, void* dk, void* dv, int64_t B,
+                                   int64_t N, int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t lddqkv,
+                                   uint32_t key, float p, hipStream_t stream) {
+    DropArgs drop;
+    if (int e = make_drop("va_attn_bwd_dropout", key, p, &drop)) return e;
+    return attn_bwd_entry("va_attn_bwd_dropout", q, k, v, o, d_o, lse2, workspace, dq, dk, dv, B, N, H, hd, ldqkv, ldo,
+                          lddqkv, drop, stream);
 }

@@ -105,6 +105,23 @@ VA_DEVINL int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// ---- dropout masks ------------------------------------------------------
+// Counter-based keep/drop decisions: one 32-bit mix of (key, pair index) serves the two elements 2*pair and
+// 2*pair+1 through its low and high 16 bits; an element is kept when its field is >= thresh16 = round(p * 65536).
+// Any kernel can therefore regenerate the mask of any element from (key, element index) alone.
+VA_DEVINL uint32_t drop_hash(uint32_t key, uint32_t pair) {
+    uint32_t x = pair * 0x9E3779B1u + key;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    x *= 0x297A2D39u;
+    x ^= x >> 15;
+    return x;
+}
+VA_DEVINL bool drop_keep(uint32_t hash, int odd, uint32_t thresh16) {
+    return ((odd ? hash >> 16 : hash & 0xffffu)) >= thresh16;
+}
+
 // ---- host side ------------------------------------------------------------
 #define VA_OK 0
 #define VA_ERR_INVALID VA_ERR_INVALID_ARG
@@ -113,6 +130,9 @@ VA_DEVINL int xcd_remap(int bid, int nwg) {
 #ifdef __cplusplus
 extern "C" void va_set_error(const char* fmt, ...);
 #endif
+// p -> 16-bit threshold, and the rescale 1 / (1 - thresh/65536) of the kept elements
+static inline uint32_t va_drop_thresh16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+static inline float va_drop_scale(uint32_t thresh16) { return 65536.0f / (float)(65536u - thresh16); }
 
 #define VA_CHECK_ARG(cond, ...)                \
     do {                                       \

@@ -431,6 +431,44 @@ __global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __rest
     }
 }
 
+// out = [resid +] keep(in) * scale over a contiguous [rows, cols] matrix (cols % 8 == 0), element index
+// row * cols + col.  in / out independently f32 or bf16; in place allowed.  A thread handles 8 elements.
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void dropout_kernel(const TIN* __restrict__ in, TOUT* __restrict__ out,
+                                                      const float* __restrict__ resid, int64_t n8, uint32_t key,
+                                                      uint32_t thresh16, float scale) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n8) return;
+    const int64_t e0 = g * 8;
+    float v[8];
+    if (sizeof(TIN) == 4) {
+        const f32x4_t a = *(const f32x4_t*)((const float*)in + e0), b = *(const f32x4_t*)((const float*)in + e0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    } else {
+        const u32x4_t a = *(const u32x4_t*)((const bf16_t*)in + e0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(a[j] << 16); v[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t hsh = drop_hash(key, (uint32_t)(e0 / 2 + j));
+        v[2 * j] = drop_keep(hsh, 0, thresh16) ? __fmul_rn(v[2 * j], scale) : 0.f;       // rounded product: never
+        v[2 * j + 1] = drop_keep(hsh, 1, thresh16) ? __fmul_rn(v[2 * j + 1], scale) : 0.f;   // fused with the add
+    }
+    if (resid != nullptr) {
+        const f32x4_t a = *(const f32x4_t*)(resid + e0), b = *(const f32x4_t*)(resid + e0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+    }
+    if (sizeof(TOUT) == 4) {
+        *(f32x4_t*)((float*)out + e0) = (f32x4_t){v[0], v[1], v[2], v[3]};
+        *(f32x4_t*)((float*)out + e0 + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+    } else {
+        *(u32x4_t*)((bf16_t*)out + e0) = (u32x4_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    }
+}
+
 }  // namespace
 
 // ===================================================================================================
@@ -616,5 +654,27 @@ extern "C" int va_normalize_u8(const uint8_t* frames, float* out, int64_t B, int
     hipLaunchKernelGGL(normalize_u8_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, frames, out, quads,
                        H * W, T, mean, stdv);
     VA_CHECK_LAUNCH("va_normalize_u8");
+    return VA_OK;
+}
+
+extern "C" int va_dropout(const void* in, int in_bf16, void* out, int out_bf16, const float* resid, int64_t n,
+                          uint32_t key, float p, hipStream_t stream) {
+    VA_CHECK_ARG(in && out, "va_dropout: null operand");
+    VA_CHECK_ARG(n > 0 && n % 8 == 0 && n / 2 < (1ll << 32), "va_dropout: n=%lld must be a positive multiple of 8 below 2^33", (long long)n);
+    VA_CHECK_ARG(p >= 0.f && p < 1.f, "va_dropout: p=%f outside [0,1)", (double)p);
+    VA_CHECK_ARG(((uintptr_t)in | (uintptr_t)out | (uintptr_t)resid) % 16 == 0, "va_dropout: misaligned operand");
+    const uint32_t thresh = va_drop_thresh16(p);
+    const float scale = va_drop_scale(thresh);
+    const int64_t n8 = n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256)), block(256);
+    if (in_bf16 && out_bf16)
+        hipLaunchKernelGGL((dropout_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, resid, n8, key, thresh, scale);
+    else if (!in_bf16 && out_bf16)
+        hipLaunchKernelGGL((dropout_kernel<float, bf16_t>), grid, block, 0, stream, (const float*)in, (bf16_t*)out, resid, n8, key, thresh, scale);
+    else if (!in_bf16 && !out_bf16)
+        hipLaunchKernelGGL((dropout_kernel<float, float>), grid, block, 0, stream, (const float*)in, (float*)out, resid, n8, key, thresh, scale);
+    else
+        hipLaunchKernelGGL((dropout_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)in, (float*)out, resid, n8, key, thresh, scale);
+    VA_CHECK_LAUNCH("va_dropout");
     return VA_OK;
 }

@@ -15,8 +15,12 @@ The engine replaces the eager op sequence of the reference's `VideoViTEncoder.fo
   the data-parallel reducer all-reduces as soon as the block's backward has been enqueued.
 
 The residual stream, LayerNorm statistics, softmax statistics and all accumulators are f32; GEMM and
-attention operands are bf16.  Dropout (p = 0.1 in the reference's blocks, swm:752) is the identity here:
-this engine implements the eval-mode arithmetic the parity fixtures are defined on.
+attention operands are bf16.
+
+Dropout (p = 0.1 in the reference's blocks, swm:752) is the identity in eval mode.  In training mode the three
+dropouts of a block (attention probabilities swm:326, after GELU swm:700, after fc2 swm:702) use counter-based
+masks: each site of each block gets a 32-bit key per forward, the forward kernels derive keep/drop from
+(key, element index), and the backward regenerates the same decisions from the saved keys -- no mask is stored.
 """
 from __future__ import annotations
 
@@ -125,6 +129,21 @@ class EncoderContext:
     x_last: Optional[torch.Tensor] = None
     mean_f: Optional[torch.Tensor] = None
     rstd_f: Optional[torch.Tensor] = None
+    drop: Optional["DropPlan"] = None
+
+
+@dataclass
+class DropPlan:
+    """Training-mode dropout of one forward: per block the probabilities and keys of its three sites
+    (attention probabilities, after GELU, after fc2)."""
+    p: List[Tuple[float, float, float]]
+    keys: List[Tuple[int, int, int]]
+
+    @staticmethod
+    def draw(p: List[Tuple[float, float, float]]) -> "DropPlan":
+        """Keys from torch's default CPU generator, so torch.manual_seed makes a training run repeatable."""
+        k = torch.randint(0, 2 ** 32, (len(p), 3), dtype=torch.int64).tolist()
+        return DropPlan([tuple(float(v) for v in t) for t in p], [tuple(int(v) for v in t) for t in k])
 
 
 class EncoderEngine:
@@ -158,8 +177,9 @@ class EncoderEngine:
         return B, grid, N
 
     # ---------------------------------------------------------------- forward
-    def forward(self, P: Dict[str, torch.Tensor], video: torch.Tensor, save: bool):
+    def forward(self, P: Dict[str, torch.Tensor], video: torch.Tensor, save: bool, drop: Optional[DropPlan] = None):
         """P: name -> f32 device tensor (parameters and the rope.inv_freq_* buffers).
+        drop: training-mode dropout plan, None for the eval-mode arithmetic.
         Returns (features (B,N,D) f32, EncoderContext or None)."""
         cfg = self.cfg
         dev = video.device
@@ -178,7 +198,9 @@ class EncoderEngine:
         x = new(D, F32)
         ops.gemm_nt(patches, Wc.fwd("pe", P["tubelet_embed.projection.weight"]), ops.EPI_F32, x,
                     bias=P["tubelet_embed.projection.bias"])
-        ctx = EncoderContext(cfg, B, N, grid, tables, patches) if save else None
+        ctx = EncoderContext(cfg, B, N, grid, tables, patches, drop=drop) if save else None
+        if drop is not None and (len(drop.p) != cfg.depth or len(drop.keys) != cfg.depth):
+            raise ValueError("dropout plan does not match the encoder depth")
 
         # without a backward the activations of one block are recycled for the next
         scratch: Dict[str, torch.Tensor] = {}
@@ -210,7 +232,9 @@ class EncoderEngine:
             attn = buf("attn", D, BF16)
             lse2 = torch.empty(B * H, N, dtype=F32, device=dev) if save else scratch.setdefault(
                 "lse2", torch.empty(B * H, N, dtype=F32, device=dev))
-            ops.attn_fwd(qkv, B, N, H, attn, lse2)
+            pa, p1, p2 = drop.p[i] if drop is not None else (0.0, 0.0, 0.0)
+            ka, k1, k2 = drop.keys[i] if drop is not None else (0, 0, 0)
+            ops.attn_fwd(qkv, B, N, H, attn, lse2, drop_key=ka, drop_p=pa)
             x_mid = buf("x_mid", D, F32) if save else buf("x_mid" + str(i & 1), D, F32)
             ops.gemm_nt(attn, Wc.fwd(p + "out", P[p + "attn.out_proj.weight"]), ops.EPI_F32, x_mid, resid=x)
             mean2, rstd2 = stat("mean2"), stat("rstd2")
@@ -219,9 +243,16 @@ class EncoderEngine:
             pre, act = buf("pre", 4 * D, BF16), buf("act", 4 * D, BF16)
             ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BIAS_GELU, pre, out2=act,
                         bias=P[p + "mlp.0.bias"])
+            if p1 > 0:
+                ops.dropout(act, k1, p1)                 # in place: the saved activation is the dropped one
             x_next = buf("x_out", D, F32) if save else buf("x_out" + str(i & 1), D, F32)
-            ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next, bias=P[p + "mlp.3.bias"],
-                        resid=x_mid)
+            if p2 > 0:
+                ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next,
+                            bias=P[p + "mlp.3.bias"])
+                ops.dropout(x_next, k2, p2, resid=x_mid)
+            else:
+                ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next,
+                            bias=P[p + "mlp.3.bias"], resid=x_mid)
             if save:
                 ctx.blocks.append(_BlockSaved(x, mean1, rstd1, ln1, qkv, attn, lse2, x_mid, mean2, rstd2, ln2, pre, act))
             x = x_next
@@ -264,6 +295,8 @@ class EncoderEngine:
         d_small = torch.empty(M, D, dtype=BF16, device=dev)       # dLN inputs / dO
         d_wide = torch.empty(M, 4 * D, dtype=BF16, device=dev)    # d(pre-activation)
         dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+        drop = ctx.drop
+        g_drop = torch.empty(M, D, dtype=BF16, device=dev) if drop is not None else None   # dropped MLP-branch gradient
 
         tail = carve([("norm.weight", (D,)), ("norm.bias", (D,))])
         ops.layernorm_bwd(gy, ctx.x_last, P["norm.weight"], ctx.mean_f, ctx.rstd_f, None, g_a, g_bf,
@@ -276,9 +309,14 @@ class EncoderEngine:
             p = f"blocks.{i}."
             s = ctx.blocks[i]
             flat = carve([(p + n, tuple(P[p + n].shape)) for n in BLOCK_PARAM_NAMES])
-            # ---- MLP
-            ops.gemm_nt(g_bf, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_GELU_BWD, d_wide, aux=s.pre)
-            ops.gemm_tn_accum(g_bf, s.act, grads[p + "mlp.3.weight"], dbias=grads[p + "mlp.3.bias"])
+            pa, p1, p2 = drop.p[i] if drop is not None else (0.0, 0.0, 0.0)
+            ka, k1, k2 = drop.keys[i] if drop is not None else (0, 0, 0)
+            # ---- MLP (the residual path keeps g_a / g_bf; only the branch gradient passes the fc2 dropout)
+            g_mlp = ops.dropout(g_bf, k2, p2, out=g_drop) if p2 > 0 else g_bf
+            ops.gemm_nt(g_mlp, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_GELU_BWD, d_wide, aux=s.pre)
+            if p1 > 0:
+                ops.dropout(d_wide, k1, p1)             # the mask commutes with the GELU derivative
+            ops.gemm_tn_accum(g_mlp, s.act, grads[p + "mlp.3.weight"], dbias=grads[p + "mlp.3.bias"])
             ops.gemm_nt(d_wide, Wc.bwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BF16, d_small)
             ops.gemm_tn_accum(d_wide, s.ln2, grads[p + "mlp.0.weight"], dbias=grads[p + "mlp.0.bias"])
             ops.layernorm_bwd(d_small, s.x_mid, P[p + "norm2.weight"], s.mean2, s.rstd2, g_a, g_b, g_bf,
@@ -286,7 +324,7 @@ class EncoderEngine:
             # ---- attention
             ops.gemm_nt(g_bf, Wc.bwd(p + "out", P[p + "attn.out_proj.weight"]), ops.EPI_BF16, d_small)
             ops.gemm_tn_accum(g_bf, s.attn, grads[p + "attn.out_proj.weight"])
-            ops.attn_bwd(s.qkv, s.attn, d_small, s.lse2, dqkv, B, N, H)
+            ops.attn_bwd(s.qkv, s.attn, d_small, s.lse2, dqkv, B, N, H, drop_key=ka, drop_p=pa)
             ops.rope3d_qk_(dqkv, tables, grid, inverse=True)
             ops.gemm_nt(dqkv, Wc.bwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, d_small)
             ops.gemm_tn_accum(dqkv, s.ln1, grads[p + "attn.qkv_proj.weight"])

@@ -178,9 +178,10 @@ def rope3d_qk_(qkv: torch.Tensor, tables: torch.Tensor, grid: Tuple[int, int, in
 
 # ------------------------------------------------------------------ attention
 def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2: torch.Tensor,
-             tokens_per_timestep: int = 0):
+             tokens_per_timestep: int = 0, drop_key: int = 0, drop_p: float = 0.0):
     """qkv: packed [B*N, 3*D] bf16 (q | k | v thirds); out [B*N, D] bf16; lse2 [B*H, N] f32.
-    tokens_per_timestep > 0 selects the predictor's block-causal mask (forward only)."""
+    tokens_per_timestep > 0 selects the predictor's block-causal mask (forward only).
+    drop_p > 0: training-mode dropout on the attention probabilities, masks derived from drop_key."""
     _need(qkv, BF16, "qkv"); _need(out, BF16, "out"); _need(lse2, F32, "lse2")
     M, W3 = qkv.shape
     D = W3 // 3
@@ -190,14 +191,20 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2:
     es = qkv.element_size()
     ptrs = (qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out), _p(lse2))
     if tokens_per_timestep > 0:
+        if drop_p > 0:
+            raise ValueError("attn_fwd: dropout is not available with the block-causal mask")
         check(_lib.load().va_attn_fwd_block_causal(*ptrs, B, N, H, hd, _ld(qkv), _ld(out), tokens_per_timestep,
                                                    _stream()), "va_attn_fwd_block_causal")
+    elif drop_p > 0:
+        check(_lib.load().va_attn_fwd_dropout(*ptrs, B, N, H, hd, _ld(qkv), _ld(out), drop_key & 0xffffffff,
+                                              float(drop_p), _stream()), "va_attn_fwd_dropout")
     else:
         check(_lib.load().va_attn_fwd(*ptrs, B, N, H, hd, _ld(qkv), _ld(out), _stream()), "va_attn_fwd")
     return out
 
 
-def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int):
+def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int, drop_key: int = 0, drop_p: float = 0.0):
+    """drop_key / drop_p: the values the forward ran with (the masks are regenerated, not stored)."""
     _need(qkv, BF16, "qkv"); _need(out, BF16, "out"); _need(d_out, BF16, "d_out"); _need(dqkv, BF16, "dqkv")
     M, W3 = qkv.shape
     D = W3 // 3
@@ -205,12 +212,33 @@ def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int):
         raise ValueError("attn_bwd: inconsistent shapes")
     hd = D // H
     es = 2
-    delta = torch.empty(_lib.load().va_attn_bwd_workspace_bytes(B, N, H) // 4, dtype=F32, device=qkv.device)   # workspace
-    check(_lib.load().va_attn_bwd(qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out),
-                                  _p(d_out), _p(lse2), _p(delta), dqkv.data_ptr(), dqkv.data_ptr() + D * es,
-                                  dqkv.data_ptr() + 2 * D * es, B, N, H, hd, _ld(qkv), _ld(out), _ld(dqkv), _stream()),
-          "va_attn_bwd")
+    lib = _lib.load()
+    delta = torch.empty(lib.va_attn_bwd_workspace_bytes(B, N, H) // 4, dtype=F32, device=qkv.device)   # workspace
+    args = (qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out), _p(d_out), _p(lse2),
+            _p(delta), dqkv.data_ptr(), dqkv.data_ptr() + D * es, dqkv.data_ptr() + 2 * D * es, B, N, H, hd, _ld(qkv),
+            _ld(out), _ld(dqkv))
+    if drop_p > 0:
+        check(lib.va_attn_bwd_dropout(*args, drop_key & 0xffffffff, float(drop_p), _stream()), "va_attn_bwd_dropout")
+    else:
+        check(lib.va_attn_bwd(*args, _stream()), "va_attn_bwd")
     return dqkv
+
+
+def dropout(x: torch.Tensor, key: int, p: float, out: Optional[torch.Tensor] = None,
+            resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = [resid +] keep(x) / (1 - p) with the counter-based masks of the library (training-mode nn.Dropout,
+    swm:700-702).  x / out: contiguous f32 or bf16 of one shape (out defaults to x, in place); resid f32."""
+    out = x if out is None else out
+    for t, name in ((x, "x"), (out, "out")):
+        if t.dtype not in (BF16, F32) or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError(f"dropout: {name} must be a contiguous f32/bf16 device tensor")
+    if out.shape != x.shape or (resid is not None and (resid.shape != x.shape or resid.dtype != F32
+                                                       or not resid.is_contiguous())):
+        raise ValueError("dropout: shape / dtype mismatch")
+    check(_lib.load().va_dropout(_p(x), int(x.dtype == BF16), _p(out), int(out.dtype == BF16),
+                                 _p(resid) if resid is not None else None, x.numel(), key & 0xffffffff, float(p),
+                                 _stream()), "va_dropout")
+    return out
 
 
 # ------------------------------------------------------------------ predictor (inference)

@@ -14,7 +14,6 @@ Reference citations: swm = surgical_world_model.py of HananKibria/VIT.
 from __future__ import annotations
 
 import math
-import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -23,7 +22,7 @@ import torch.nn.functional as F
 
 from . import ops, predictor_engine
 from ._lib import VitAmdError
-from .encoder_engine import EncoderConfig, EncoderEngine, WeightCache, encoder_param_names
+from .encoder_engine import DropPlan, EncoderConfig, EncoderEngine, WeightCache, encoder_param_names
 
 _ROPE_SPLIT = {"t_dim": 256, "h_dim": 384, "w_dim": 384}          # swm:731-735
 
@@ -150,7 +149,7 @@ class _EncoderFn(torch.autograd.Function):
             raise NotImplementedError("gradient with respect to the input video is not implemented")
         P = module._tensor_table(params)
         save = any(ctx.needs_input_grad[2:])
-        out, ectx = module._engine.forward(P, video, save=save)
+        out, ectx = module._engine.forward(P, video, save=save, drop=module._dropout_plan())
         ctx.module, ctx.ectx, ctx.P = module, ectx, P
         return out
 
@@ -169,8 +168,6 @@ class _EncoderFn(torch.autograd.Function):
 
 class VideoViTEncoder(nn.Module):
     """Tubelet embedding + 3-D RoPE transformer encoder (swm:717-817) on the MI355X engine."""
-
-    _warned_no_dropout = False
 
     def __init__(self, img_size=224, num_frames=16, tubelet_size=(2, 16, 16), in_channels=3, embed_dim=1024,
                  depth=12, num_heads=12, use_grad_checkpoint=False):
@@ -201,6 +198,15 @@ class VideoViTEncoder(nn.Module):
         """Attach a `vit_amd.ddp.BucketReducer`: gradients are then averaged across ranks inside backward."""
         self._grad_reducer = reducer
 
+    def _dropout_plan(self) -> Optional[DropPlan]:
+        """Training mode: the probabilities of each block's nn.Dropout modules (swm:263, 700-702; 0.1 as built,
+        a block whose modules are in eval mode or set to p = 0 contributes zeros) and fresh keys for this forward."""
+        ps = [tuple(d.p if d.training else 0.0 for d in (blk.attn.dropout, blk.mlp[2], blk.mlp[4]))
+              for blk in self.blocks]
+        if not any(v > 0 for t in ps for v in t):
+            return None
+        return DropPlan.draw(ps)
+
     def _tensor_table(self, params) -> Dict[str, torch.Tensor]:
         P = dict(zip(self._param_order, params))
         P["rope.inv_freq_t"], P["rope.inv_freq_h"], P["rope.inv_freq_w"] = \
@@ -216,11 +222,6 @@ class VideoViTEncoder(nn.Module):
     def forward(self, video: torch.Tensor) -> torch.Tensor:
         if not video.is_cuda:
             raise VitAmdError("VideoViTEncoder.forward needs a HIP device tensor: vit_amd has no CPU fallback")
-        if self.training and not VideoViTEncoder._warned_no_dropout:
-            # the reference's blocks carry nn.Dropout(0.1) (swm:263, 700-702) that is active under model.train()
-            VideoViTEncoder._warned_no_dropout = True
-            warnings.warn("vit_amd.VideoViTEncoder computes the eval-mode arithmetic in training mode too: the "
-                          "p=0.1 dropouts inside the encoder blocks are not applied", stacklevel=2)
         named = dict(self.named_parameters())
         params = [named[n] for n in self._param_order]
         for n, p in zip(self._param_order, params):
