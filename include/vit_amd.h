@@ -111,25 +111,25 @@ int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
 /* ---- training-mode dropout ---------------------------------------------------------------------------
  * The reference's encoder block applies nn.Dropout to the attention probabilities (swm:326, inside
  * scaled_dot_product_attention when the module is in training mode) and after both MLP linears (swm:700-702).
- * Keep/drop decisions here are a pure function of (key, element index), so the backward kernels regenerate
- * the mask of the forward instead of reading a stored one: element e keeps when the 16-bit field
- * (e odd ? h >> 16 : h & 0xffff) of h = mix(e / 2 * 0x9E3779B1 + key) is >= round(p * 65536), with
- * mix(x): x ^= x >> 15; x *= 0x2C1B3C6D; x ^= x >> 12; x *= 0x297A2D39; x ^= x >> 15 (32-bit), and kept values are
- * multiplied by 65536 / (65536 - round(p * 65536)).  The random STREAM differs from torch's Philox generator; the
- * distribution (independent Bernoulli(1-p) per element) is the same.
+ * Keep/drop decisions here are a pure function of (key, element position), so the backward kernels regenerate
+ * the mask of the forward instead of reading a stored one.  Two neighbouring elements share one 32-bit word
+ *     h = mix(pair * 0x9E3779B1 + key),   mix(w): w ^= w >> 16; w *= 0x21F0AAAD; w ^= w >> 15   (mod 2^32);
+ * the even element of the pair is kept when h & 0xffff >= T, the odd one when h >> 16 >= T, T = round(p * 65536),
+ * and kept values are multiplied by 65536 / (65536 - T).  The random STREAM differs from torch's Philox
+ * generator; the distribution (independent Bernoulli(1 - p) per element) is the same.
  *
  * va_attn_fwd_dropout / va_attn_bwd_dropout: as va_attn_fwd / va_attn_bwd with dropout of probability p on the
- * probabilities that multiply V.  Element (q, k) of head-batch bh uses key + bh * 0x9E3779B9 and element index
- * q * NS + k, NS = N rounded up to even (mod 2^32).  The backward must be given the forward's key and p.
+ * probabilities that multiply V.  Element (q, k) of head-batch bh = b * H + h uses the key key + bh * 0x85EBCA6B
+ * and is field k & 1 of pair q * ceil(N / 2) + k / 2.  The backward must be given the forward's key and p.
  * p == 0 runs the plain kernels. */
 int va_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N,
                         int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, uint32_t key, float p, va_stream_t stream);
 int va_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2,
                         float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N, int64_t H, int64_t hd,
                         int64_t ldqkv, int64_t ldo, int64_t lddqkv, uint32_t key, float p, va_stream_t stream);
-/* out[e] = (resid ? resid[e] : 0) + keep(e) * in[e] * scale over n contiguous elements (n % 8 == 0); in / out are
- * f32 or bf16 as the flags say, resid is f32 or NULL; in == out is allowed.  The same call with the same key
- * applied to a gradient is the backward. */
+/* out[e] = (resid ? resid[e] : 0) + keep(e) * in[e] * scale over n contiguous elements (n % 8 == 0), element e
+ * being field e & 1 of pair e / 2; in / out are f32 or bf16 as the flags say, resid is f32 or NULL; in == out is
+ * allowed.  The same call with the same key applied to a gradient is the backward. */
 int va_dropout(const void* in, int in_bf16, void* out, int out_bf16, const float* resid, int64_t n, uint32_t key,
                float p, va_stream_t stream);
 

@@ -206,40 +206,44 @@ def drop_scale(p: float) -> float:
     return float(np.float32(65536.0) / np.float32(65536 - drop_thresh16(p)))
 
 
-def _drop_mix(pair: np.ndarray, key: np.ndarray) -> np.ndarray:
+def _drop_word(pair: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """h = mix(pair * 0x9E3779B1 + key), mix(w): w ^= w >> 16; w *= 0x21F0AAAD; w ^= w >> 15 (all mod 2^32)."""
     M = np.uint64(0xFFFFFFFF)
-    x = (pair.astype(np.uint64) * np.uint64(0x9E3779B1) + key.astype(np.uint64)) & M
-    x ^= x >> np.uint64(15)
-    x = (x * np.uint64(0x2C1B3C6D)) & M
-    x ^= x >> np.uint64(12)
-    x = (x * np.uint64(0x297A2D39)) & M
-    x ^= x >> np.uint64(15)
-    return x
+    w = (pair.astype(np.uint64) * np.uint64(0x9E3779B1) + key.astype(np.uint64)) & M
+    w ^= w >> np.uint64(16)
+    w = (w * np.uint64(0x21F0AAAD)) & M
+    w ^= w >> np.uint64(15)
+    return w
 
 
-def drop_keep_elems(key, elem: np.ndarray, p: float) -> np.ndarray:
-    """Boolean keep decision of the elements with (uint32, wrapping) indices `elem` under `key` (scalar or array)."""
-    elem = np.asarray(elem, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
-    h = _drop_mix(elem >> np.uint64(1), np.asarray(key, dtype=np.uint64) & np.uint64(0xFFFFFFFF))
-    field = np.where((elem & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+def drop_keep_pairs(key, pair: np.ndarray, odd: np.ndarray, p: float) -> np.ndarray:
+    """Keep decision of the elements (pair index mod 2^32, odd flag): the high 16-bit field of the pair's word for
+    an odd element, the low one for an even element, kept when the field >= round(p * 65536)."""
+    M = np.uint64(0xFFFFFFFF)
+    h = _drop_word(np.asarray(pair, dtype=np.uint64) & M, np.asarray(key, dtype=np.uint64) & M)
+    field = np.where(np.asarray(odd) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
     return field >= np.uint64(drop_thresh16(p))
 
 
 def drop_mask(key: int, shape, p: float) -> torch.Tensor:
-    """Multiplier tensor (0 or 1/(1-p)) of a contiguous tensor of `shape`: element index = flat index."""
-    n = int(np.prod(shape))
-    keep = drop_keep_elems(key, np.arange(n, dtype=np.uint64), p)
+    """Multiplier tensor (0 or 1/(1-p)) of a contiguous tensor of `shape`: flat element e is the (e & 1) field of
+    pair e >> 1."""
+    e = np.arange(int(np.prod(shape)), dtype=np.uint64)
+    keep = drop_keep_pairs(key, e >> np.uint64(1), e & np.uint64(1), p)
     return torch.from_numpy(keep.astype(np.float32) * np.float32(drop_scale(p))).reshape(tuple(shape))
 
 
 def attn_drop_mask(key: int, B: int, H: int, N: int, p: float) -> torch.Tensor:
     """Multiplier tensor [B, H, N, N] of the attention probabilities: head-batch bh = b*H + h uses the key
-    key + bh * 0x9E3779B9 and element index q * NS + k, NS = N rounded up to even."""
-    NS = (N + 1) & ~1
+    key + bh * 0x85EBCA6B; element (q, k) is the (k & 1) field of pair q * ceil(N / 2) + (k >> 1)."""
+    half = np.uint64((N + 1) // 2)
     bh = np.arange(B * H, dtype=np.uint64)[:, None, None]
-    keys = (np.uint64(key) + bh * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
-    elem = (np.arange(N, dtype=np.uint64)[None, :, None] * np.uint64(NS) + np.arange(N, dtype=np.uint64)[None, None, :])
-    keep = drop_keep_elems(np.broadcast_to(keys, (B * H, N, N)), np.broadcast_to(elem, (B * H, N, N)), p)
+    keys = (np.uint64(key) + bh * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    q = np.arange(N, dtype=np.uint64)[None, :, None]
+    k = np.arange(N, dtype=np.uint64)[None, None, :]
+    shape = (B * H, N, N)
+    keep = drop_keep_pairs(np.broadcast_to(keys, shape), np.broadcast_to(q * half + (k >> np.uint64(1)), shape),
+                           np.broadcast_to(k & np.uint64(1), shape), p)
     return torch.from_numpy(keep.astype(np.float32) * np.float32(drop_scale(p))).reshape(B, H, N, N)
 
 

@@ -57,6 +57,16 @@ print(f"attn_fwd: {t*1e3:.3f} ms {fl/t/1e12:.1f} TF/s")
 do = rnd((M, D)); dqkv = torch.empty_like(qkv)
 t = timeit(lambda: ops.attn_bwd(qkv, o, do, lse, dqkv, B, N, H))
 print(f"attn_bwd: {t*1e3:.3f} ms {2.5*fl/t/1e12:.1f} TF/s (5-product flops)")
+t = timeit(lambda: ops.attn_fwd(qkv, B, N, H, o, lse, drop_key=7, drop_p=0.1))
+print(f"attn_fwd dropout 0.1: {t*1e3:.3f} ms")
+t = timeit(lambda: ops.attn_bwd(qkv, o, do, lse, dqkv, B, N, H, drop_key=7, drop_p=0.1))
+print(f"attn_bwd dropout 0.1: {t*1e3:.3f} ms")
+act = torch.randn(B * N, 4 * D, device=dev).to(torch.bfloat16)
+t = timeit(lambda: ops.dropout(act, 7, 0.1))
+print(f"dropout bf16 in place [M,4D]: {t*1e3:.3f} ms {2*act.numel()*2/t/1e9:.0f} GB/s")
+xf = torch.randn(B * N, D, device=dev); rf = torch.randn(B * N, D, device=dev)
+t = timeit(lambda: ops.dropout(xf, 7, 0.1, resid=rf))
+print(f"dropout f32 + resid in place [M,D]: {t*1e3:.3f} ms {3*xf.numel()*4/t/1e9:.0f} GB/s")
 # elementwise
 xf = torch.randn(M, D, device=dev); g = torch.ones(D, device=dev); bt = torch.zeros(D, device=dev)
 mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev); y = torch.empty(M, D, dtype=BF16, device=dev)

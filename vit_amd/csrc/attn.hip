@@ -157,12 +157,15 @@ constexpr int fwd_ring_slots(int hd) { return hd == 64 ? 3 : 2; }
 // timestep s = n / tpt sees the keys of timesteps <= s (the predictor's mask, swm:1008-1028); N % tpt == 0.
 // Modes 1 and 2 are one mechanism: a per-lane key limit, applied only in tiles that reach past it.
 // DROP: dropout on the attention probabilities (swm:326, training mode): the probabilities that enter P*V are
-// masked and rescaled, the softmax normaliser is not; element (q, k) of head bh takes its decision from
-// drop_hash(key + bh * 0x9E3779B9, (q * NS + k) / 2) with NS = N rounded up to even (32-bit wrap-around).
+// masked and rescaled, the softmax normaliser is not.  Element (q, k) of head-batch bh takes its decision from
+// the word drop_mix(drop_weyl(key + bh * DROP_HEAD, q * (NS / 2) + k / 2)), field k & 1, NS = N rounded up to
+// even.  The rescale 1 / (1 - p) never touches an element: it is folded into the factor each kernel applies to
+// its accumulators on the way out (and the backward's delta is pre-divided by it).
 struct DropArgs {
     uint32_t key, thresh16;
     float scale;
 };
+VA_DEVINL uint32_t drop_half_stride(int N) { return ((uint32_t)N + 1u) >> 1; }   // NS / 2
 
 template <int HD, int MODE, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
@@ -212,6 +215,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         q_last = q_last < N ? q_last : N - 1;
         nt = ((q_last / tpt + 1) * tpt + TILE_ROWS - 1) / TILE_ROWS;
     }
+    // DROP: Weyl term of this lane's first key pair (keys 4h, 4h+1 of tile 0), and the threshold aligned to bit 16
+    const uint32_t drop_w = drop_weyl(drop.key + (uint32_t)bh * DROP_HEAD,
+                                      (uint32_t)qrow_c * drop_half_stride(N) + 2u * (uint32_t)h);
+    const uint32_t drop_thi = drop.thresh16 << 16;
     TileSrc<HD> ts;
     ts.init(ld, tid);
     auto stage = [&](int tile, int slot) {
@@ -318,15 +325,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 l += p;
             }
         if (DROP) {
-            const uint32_t key = drop.key + (uint32_t)bh * 0x9E3779B9u;
-            const uint32_t base = (uint32_t)qrow_c * (((uint32_t)N + 1u) & ~1u) + (uint32_t)(t * TILE_ROWS);
+            // registers i, i+1 (i even) hold keys t*64 + kb*32 + acc32_row(i, h) and the next one: one pair
+            const uint32_t wt = drop_w + (uint32_t)t * ((TILE_ROWS / 2) * DROP_WEYL);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) {       // registers i, i+1 are keys k, k+1 with k even
-                    const uint32_t hsh = drop_hash(key, (base + kb * 32 + acc32_row(i, h)) >> 1);
-                    st[kb][i] = drop_keep(hsh, 0, drop.thresh16) ? st[kb][i] * drop.scale : 0.f;
-                    st[kb][i + 1] = drop_keep(hsh, 1, drop.thresh16) ? st[kb][i + 1] * drop.scale : 0.f;
+                for (int i = 0; i < 16; i += 2) {
+                    const uint32_t hsh = drop_mix(wt + (uint32_t)(kb * 16 + 4 * (i >> 2) + ((i & 3) >> 1)) * DROP_WEYL);
+                    st[kb][i] = drop_keep_even(hsh, drop_thi) ? st[kb][i] : 0.f;
+                    st[kb][i + 1] = drop_keep_odd(hsh, drop_thi) ? st[kb][i + 1] : 0.f;
                 }
         }
 #pragma unroll
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     }
     l += __shfl_xor(l, 32);
     if (qrow < N) {
-        store_rows<HD>(o, 1.0f / l, O + ((int64_t)b * N + qrow) * ldo + hh * HD, h);
+        store_rows<HD>(o, (DROP ? drop.scale : 1.0f) / l, O + ((int64_t)b * N + qrow) * ldo + hh * HD, h);
         if (h == 0) LSE2[(int64_t)bh * N + qrow] = m + __log2f(l);
     }
 #ifdef VA_ATTN_PROFILE
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// delta[bh][n] = sum_d dO * O      (one 8-lane group per (token, head) for HD=64, 16 lanes for 128)
+// neg_delta[bh][n] = -mul * sum_d dO * O      (one 8-lane group per (token, head) for HD=64, 16 lanes for 128)
 // Also writes, per (bh, n), the 16-byte record the dK/dV pass feeds to the matrix pipe: -lse2 and -delta,
 // each split exactly into three bf16 terms {hi, mid | lo, 0} (8+8+8 mantissa bits), laid out as the first
 // two dwords of an MFMA operand fragment.
@@ -373,9 +380,9 @@ VA_DEVINL void split3_bf16(float x, uint32_t& d0, uint32_t& d1) {
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ DO,
-                                                         const float* __restrict__ LSE2, float* __restrict__ delta,
+                                                         const float* __restrict__ LSE2, float* __restrict__ neg_delta,
                                                          u32x4_t* __restrict__ aux, int64_t rows, int N, int H,
-                                                         int64_t ldo) {
+                                                         int64_t ldo, float mul) {
     constexpr int LPH = HD / 8;   // lanes per (row, head)
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t item = gid / LPH;             // (row, head)
@@ -398,7 +405,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     if (live && part == 0) {
         const int64_t b = row / N, n = row % N;
         const int64_t at = (b * H + hh) * N + n;
-        delta[at] = s;
+        s *= mul;              // 1, or (1 - p) when the passes fold the dropout rescale into their output factor
+        neg_delta[at] = -s;
         u32x4_t rec;
         uint32_t d0, d1;
         split3_bf16(-LSE2[at], d0, d1);
@@ -416,7 +424,7 @@ template <int HD, bool RAGGED, bool DROP = false>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
                                                           const float* __restrict__ LSE2,
-                                                          const float* __restrict__ DELTA, bf16_t* __restrict__ DQ,
+                                                          const float* __restrict__ NEG_DELTA, bf16_t* __restrict__ DQ,
                                                           int N, int H, int64_t ld, int64_t ldo, int64_t lddq, float c,
                                                           float scale, DropArgs drop) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
@@ -441,10 +449,10 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
     // A lane holds one query's column of every score tile, so -lse and -delta are per-lane constants: the
     // score / dP accumulators start from them and the MFMA chains deliver s*c - lse and dP - delta directly.
     const float lse = LSE2[(int64_t)bh * N + qrow_c];
-    const float dl = DELTA[(int64_t)bh * N + qrow_c];
+    const float ndl = NEG_DELTA[(int64_t)bh * N + qrow_c];
     f32x16_t neg_lse, neg_dl;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { neg_lse[i] = -lse; neg_dl[i] = -dl; }
+    for (int i = 0; i < 16; ++i) { neg_lse[i] = -lse; neg_dl[i] = ndl; }
 
     f32x16_t dq[CB];
 #pragma unroll
@@ -452,6 +460,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[cb][i] = 0.f;
 
+    const uint32_t drop_w = drop_weyl(drop.key + (uint32_t)bh * DROP_HEAD,
+                                      (uint32_t)qrow_c * drop_half_stride(N) + 2u * (uint32_t)h);
+    const uint32_t drop_thi = drop.thresh16 << 16;
     const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
     TileSrc<HD> ts;
     ts.init(ld, tid);
@@ -479,14 +490,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
                 vfr[ks] = row_frag<HD>(vt, kb * 32, ks, lane);
             }
             f32x16_t s = mfma32(kfr[0], qf[0], neg_lse);
-            f32x16_t dp;
-            if (DROP) {      // dP = mask * (dO V^T) - delta: delta cannot ride in the accumulator
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dp[i] = 0.f;
-                dp = mfma32(vfr[0], dof[0], dp);
-            } else {
-                dp = mfma32(vfr[0], dof[0], neg_dl);
-            }
+            f32x16_t dp = mfma32(vfr[0], dof[0], neg_dl);
 #pragma unroll
             for (int ks = 1; ks < KS; ++ks) {
                 s = mfma32(kfr[ks], qf[ks], s);
@@ -504,16 +508,13 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
                 if (ragged && t * TILE_ROWS + kb * 32 + acc32_row(i, h) >= N) p = 0.f;
                 s[i] = DROP ? p : p * dp[i];
             }
-            if (DROP) {
-                const uint32_t key = drop.key + (uint32_t)bh * 0x9E3779B9u;
-                const uint32_t base = (uint32_t)qrow_c * (((uint32_t)N + 1u) & ~1u) + (uint32_t)(t * TILE_ROWS + kb * 32);
+            if (DROP) {      // dS / scale = P * (keep ? dO V^T - delta/scale : -delta/scale); DELTA holds delta/scale
+                const uint32_t wt = drop_w + (uint32_t)(t * (TILE_ROWS / 2) + kb * 16) * DROP_WEYL;
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
-                    const uint32_t hsh = drop_hash(key, (base + acc32_row(i, h)) >> 1);
-                    const float m0 = drop_keep(hsh, 0, drop.thresh16) ? drop.scale : 0.f;
-                    const float m1 = drop_keep(hsh, 1, drop.thresh16) ? drop.scale : 0.f;
-                    s[i] *= fmaf(m0, dp[i], -dl);
-                    s[i + 1] *= fmaf(m1, dp[i + 1], -dl);
+                    const uint32_t hsh = drop_mix(wt + (uint32_t)(4 * (i >> 2) + ((i & 3) >> 1)) * DROP_WEYL);
+                    s[i] *= drop_keep_even(hsh, drop_thi) ? dp[i] : neg_dl[i];
+                    s[i + 1] *= drop_keep_odd(hsh, drop_thi) ? dp[i + 1] : neg_dl[i + 1];
                 }
             }
 #pragma unroll
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
         tile_step(t0, std::integral_constant<int, 0>{});
         if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
     }
-    if (qrow < N) store_rows<HD>(dq, scale, DQ + ((int64_t)b * N + qrow) * lddq + hh * HD, h);
+    if (qrow < N) store_rows<HD>(dq, DROP ? scale * drop.scale : scale, DQ + ((int64_t)b * N + qrow) * lddq + hh * HD, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,17 +539,18 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
 // carries the three bf16 terms of -lse2[query] (or -delta[query]) in k = 0..2 and whose B operand is 1.0
 // there; the chains then deliver s*c - lse2 and dP - delta directly.  K carries the softmax scale.
 // ------------------------------------------------------------------------------------------------
-template <int HD>
-constexpr int dkv_stage_bytes() { return 2 * TILE_ROWS * HD * 2 + TILE_ROWS * 16; }   // Q | dO | records
+template <int HD, bool DROP>   // Q | dO | records | DROP: f32 -delta of the tile's queries
+constexpr int dkv_stage_bytes() { return 2 * TILE_ROWS * HD * 2 + TILE_ROWS * 16 + (DROP ? TILE_ROWS * 4 : 0); }
 
 template <int HD, bool RAGGED, bool DROP = false>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
-                                                           const u32x4_t* __restrict__ AUX, bf16_t* __restrict__ DK,
+                                                           const u32x4_t* __restrict__ AUX,
+                                                           const float* __restrict__ NEG_DELTA, bf16_t* __restrict__ DK,
                                                            bf16_t* __restrict__ DV, int N, int H, int64_t ld,
                                                            int64_t ldo, int64_t lddq, float c, float scale, DropArgs drop) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
-    constexpr int STAGE = dkv_stage_bytes<HD>();
+    constexpr int STAGE = dkv_stage_bytes<HD, DROP>();
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE] | 16 zero bytes
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -579,6 +581,13 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[cb][i] = 0.f; dv[cb][i] = 0.f; }
 
+    // DROP: Weyl term of (query 4h, this lane's key), its step per query, and the shift that moves this key's
+    // field (low half for an even key) to the top of the word
+    const uint32_t drop_qstep = drop_half_stride(N) * DROP_WEYL;
+    const uint32_t drop_w = drop_weyl(drop.key + (uint32_t)bh * DROP_HEAD, (uint32_t)krow_c >> 1) +
+                            4u * (uint32_t)h * drop_qstep;
+    const uint32_t drop_sh = (krow_c & 1) ? 0u : 16u;
+    const uint32_t drop_thi = drop.thresh16 << 16;
     const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
     TileSrc<HD> ts_q, ts_do;
     ts_q.init(ld, tid);
@@ -591,6 +600,11 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
             int r = tile * TILE_ROWS + lane;
             r = r < N ? r : N - 1;
             glds16(aux_b + r, nb + 2 * TB);
+        }
+        if (DROP && wave == 1) {   // the same queries' -delta as plain f32, read back per register in the mask step
+            int r = tile * TILE_ROWS + lane;
+            r = r < N ? r : N - 1;
+            glds4(NEG_DELTA + (int64_t)bh * N + r, nb + 2 * TB + TILE_ROWS * 16);
         }
     };
     stage(0, 0);
@@ -618,14 +632,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
             s = mfma32(__builtin_bit_cast(bf16x8_t, a_lse), ones, s);       // [query][key] = -lse2[query]
-            f32x16_t nd;                                                    // DROP: -delta kept apart from dP
-            if (DROP) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) nd[i] = 0.f;
-                nd = mfma32(__builtin_bit_cast(bf16x8_t, a_dl), ones, nd);
-            } else {
-                dp = mfma32(__builtin_bit_cast(bf16x8_t, a_dl), ones, dp);  //               -delta[query]
-            }
+            dp = mfma32(__builtin_bit_cast(bf16x8_t, a_dl), ones, dp);      //               -delta[query]
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s = mfma32(qfr[ks], kf[ks], s);
@@ -642,20 +649,28 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
             f32x16_t pr;
             const bool ragged = RAGGED && (t == nt - 1);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float p = fast_exp2(s[i]);
-                if (ragged && t * TILE_ROWS + qb * 32 + acc32_row(i, h) >= N) p = 0.f;
-                if (DROP) {      // element (query, key = this lane's row): the pair's field is chosen by the key's parity
-                    const uint32_t qi = (uint32_t)(t * TILE_ROWS + qb * 32 + acc32_row(i, h));
-                    const uint32_t e = (qi < (uint32_t)N ? qi : (uint32_t)N - 1) * (((uint32_t)N + 1u) & ~1u) + (uint32_t)krow_c;
-                    const uint32_t hsh = drop_hash(drop.key + (uint32_t)bh * 0x9E3779B9u, e >> 1);
-                    const float mk = drop_keep(hsh, (int)(e & 1), drop.thresh16) ? drop.scale : 0.f;
-                    pr[i] = p * mk;
-                    s[i] = p * fmaf(mk, dp[i], nd[i]);
-                } else {
-                    pr[i] = p;
-                    s[i] = p * dp[i];
+            for (int g = 0; g < 4; ++g) {
+                f32x4_t nd;        // DROP: -delta of registers 4g..4g+3 (queries qb*32 + 8g + 4h + 0..3), what dP - delta
+                                   // is for a dropped element
+                if (DROP) nd = *(const f32x4_t*)(qt + 2 * TB + TILE_ROWS * 16 + (qb * 32 + 8 * g + 4 * h) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    float p = fast_exp2(s[i]);
+                    if (ragged && t * TILE_ROWS + qb * 32 + acc32_row(i, h) >= N) p = 0.f;
+                    if (DROP) {      // one word per element here: the pair partner (key ^ 1) lives in the neighbouring lane
+                        const uint32_t qi = (uint32_t)(t * TILE_ROWS + qb * 32 + 8 * g + j);
+                        const uint32_t hsh = drop_mix(drop_w + qi * drop_qstep);
+                        const bool keep = (hsh << drop_sh) >= drop_thi;
+                        pr[i] = keep ? p : 0.f;
+                        s[i] = p * (keep ? dp[i] : nd[j]);
+                    } else {
+                        pr[i] = p;
+                        s[i] = p * dp[i];
+                    }
                 }
+                // keep the four groups' hash chains apart: interleaved, their temporaries push the kernel into spills
+                if (DROP) __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
@@ -674,8 +689,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
         if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
     }
     if (krow < N) {
-        store_rows<HD>(dk, scale, DK + ((int64_t)b * N + krow) * lddq + hh * HD, h);
-        store_rows<HD>(dv, 1.0f, DV + ((int64_t)b * N + krow) * lddq + hh * HD, h);
+        store_rows<HD>(dk, DROP ? scale * drop.scale : scale, DK + ((int64_t)b * N + krow) * lddq + hh * HD, h);
+        store_rows<HD>(dv, DROP ? drop.scale : 1.0f, DV + ((int64_t)b * N + krow) * lddq + hh * HD, h);
     }
 }
 
@@ -733,26 +748,29 @@ int bwd_launch_as(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_
                   const float* lse2, float* workspace, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H,
                   int64_t ld, int64_t ldo, int64_t lddq, DropArgs drop, hipStream_t stream) {
     constexpr int LDS_DQ = 2 * 2 * TILE_ROWS * HD * 2;
-    constexpr int LDS_DKV = 2 * dkv_stage_bytes<HD>() + 16;
+    constexpr int LDS_DKV = 2 * dkv_stage_bytes<HD, DROP>() + 16;
     static bool f1[64] = {}, f2[64] = {};
     if (int e = set_lds(attn_bwd_dq_kernel<HD, RAGGED, DROP>, LDS_DQ, f1, "va_attn_bwd")) return e;
-    if (int e = set_lds(attn_bwd_dkv_kernel<HD, RAGGED, DROP>, LDS_DKV, f2, "va_attn_bwd")) return e;
+    // With the mask code the whole-tile build of the dK/dV pass spills (its precomputed tile addresses stay live
+    // across the hash temporaries); the build that clamps rows per tile does not and is correct for every N.
+    constexpr bool RAGGED_DKV = RAGGED || DROP;
+    if (int e = set_lds(attn_bwd_dkv_kernel<HD, RAGGED_DKV, DROP>, LDS_DKV, f2, "va_attn_bwd")) return e;
     const float scale = 1.0f / sqrtf((float)HD);
     const float c = 1.4426950408889634f * scale;
     const int64_t rows = (int64_t)B * N;
     const int64_t threads = rows * H * (HD / 8);
-    // workspace: [B*H*N] 16-byte records for the dK/dV pass, then [B*H*N] f32 delta for the dQ pass
+    // workspace: [B*H*N] 16-byte records for the dK/dV pass, then [B*H*N] f32 -delta
     u32x4_t* aux = (u32x4_t*)workspace;
     float* delta = workspace + 4 * rows * H;
     hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, o, d_o,
-                       lse2, delta, aux, rows, N, H, ldo);
+                       lse2, delta, aux, rows, N, H, ldo, DROP ? 1.0f / drop.scale : 1.0f);
     VA_CHECK_LAUNCH("va_attn_bwd(delta)");
     const dim3 grid((N + 127) / 128, B * H);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, RAGGED, DROP>), grid, dim3(256), LDS_DQ, stream, q, k, v, d_o, lse2,
                        delta, dq, N, H, ld, ldo, lddq, c, scale, drop);
     VA_CHECK_LAUNCH("va_attn_bwd(dq)");
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, RAGGED, DROP>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux, dk,
-                       dv, N, H, ld, ldo, lddq, c, scale, drop);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, RAGGED_DKV, DROP>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux, delta,
+                       dk, dv, N, H, ld, ldo, lddq, c, scale, drop);
     VA_CHECK_LAUNCH("va_attn_bwd(dkv)");
     return VA_OK;
 }

@@ -43,6 +43,11 @@ VA_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// The 4-byte form: lane l lands at lds_wave_base + 4*l.
+VA_DEVINL void glds4(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc, (lds_ptr_t)lds_wave_base, 4, 0, 0);
+}
+
 // Transposed LDS read: within each group of 16 lanes a 4-row x 16-column block of 16-bit words is
 // delivered column-major (lane i of the group receives column i, row q in element q).  Lane 4q+p of the
 // group supplies the address of row q, columns 4p..4p+3 (8-byte aligned).  EXEC must be all ones.
@@ -106,21 +111,23 @@ VA_DEVINL int xcd_remap(int bid, int nwg) {
 }
 
 // ---- dropout masks ------------------------------------------------------
-// Counter-based keep/drop decisions: one 32-bit mix of (key, pair index) serves the two elements 2*pair and
-// 2*pair+1 through its low and high 16 bits; an element is kept when its field is >= thresh16 = round(p * 65536).
-// Any kernel can therefore regenerate the mask of any element from (key, element index) alone.
-VA_DEVINL uint32_t drop_hash(uint32_t key, uint32_t pair) {
-    uint32_t x = pair * 0x9E3779B1u + key;
-    x ^= x >> 15;
-    x *= 0x2C1B3C6Du;
-    x ^= x >> 12;
-    x *= 0x297A2D39u;
-    x ^= x >> 15;
-    return x;
+// Counter-based keep/drop decisions.  Elements 2*pair and 2*pair+1 share one 32-bit word
+//     h = mix(pair * DROP_WEYL + key),   mix(w): w ^= w >> 16; w *= DROP_MUL; w ^= w >> 15
+// and are kept when their 16-bit field (low half for the even element, high half for the odd one) is
+// >= thresh16 = round(p * 65536).  Any kernel can therefore regenerate the decision of any element from
+// (key, element index) alone, and a kernel that walks consecutive pairs advances the Weyl term by additions.
+// The compares work on the fields in place: with thi = thresh16 << 16, "high field >= thresh16" is h >= thi and
+// "low field >= thresh16" is (h << 16) >= thi.
+constexpr uint32_t DROP_WEYL = 0x9E3779B1u, DROP_MUL = 0x21F0AAADu, DROP_HEAD = 0x85EBCA6Bu;
+VA_DEVINL uint32_t drop_weyl(uint32_t key, uint32_t pair) { return pair * DROP_WEYL + key; }
+VA_DEVINL uint32_t drop_mix(uint32_t w) {
+    w ^= w >> 16;
+    w *= DROP_MUL;
+    w ^= w >> 15;
+    return w;
 }
-VA_DEVINL bool drop_keep(uint32_t hash, int odd, uint32_t thresh16) {
-    return ((odd ? hash >> 16 : hash & 0xffffu)) >= thresh16;
-}
+VA_DEVINL bool drop_keep_even(uint32_t h, uint32_t thi) { return (h << 16) >= thi; }
+VA_DEVINL bool drop_keep_odd(uint32_t h, uint32_t thi) { return h >= thi; }
 
 // ---- host side ------------------------------------------------------------
 #define VA_OK 0

@@ -450,11 +450,13 @@ __global__ __launch_bounds__(256) void dropout_kernel(const TIN* __restrict__ in
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(a[j] << 16); v[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u); }
     }
+    const uint32_t thi = thresh16 << 16;
+    const uint32_t w0 = drop_weyl(key, (uint32_t)(e0 / 2));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t hsh = drop_hash(key, (uint32_t)(e0 / 2 + j));
-        v[2 * j] = drop_keep(hsh, 0, thresh16) ? __fmul_rn(v[2 * j], scale) : 0.f;       // rounded product: never
-        v[2 * j + 1] = drop_keep(hsh, 1, thresh16) ? __fmul_rn(v[2 * j + 1], scale) : 0.f;   // fused with the add
+    for (int j = 0; j < 4; ++j) {       // rounded products: never fused with the residual add
+        const uint32_t hsh = drop_mix(w0 + (uint32_t)j * DROP_WEYL);
+        v[2 * j] = drop_keep_even(hsh, thi) ? __fmul_rn(v[2 * j], scale) : 0.f;
+        v[2 * j + 1] = drop_keep_odd(hsh, thi) ? __fmul_rn(v[2 * j + 1], scale) : 0.f;
     }
     if (resid != nullptr) {
         const f32x4_t a = *(const f32x4_t*)(resid + e0), b = *(const f32x4_t*)(resid + e0 + 4);
