@@ -40,7 +40,9 @@ def rel_err(a, b):
 @pytest.mark.parametrize("M,N,K,tile", [(8, 1024, 1024, 128), (300, 3072, 1024, 128), (1000, 1024, 1536, 128),
                                         (2048, 4096, 1024, 256), (2048 + 17, 1024, 4096, 256), (513, 3072, 1024, 256),
                                         (300, 256, 128, 256), (2048, 1024, 1536, 256), (2048, 4096, 1024, 1256), (2048, 3072, 1024, 2256), (700, 1024, 128, 256), (700, 1024, 192, 256),
-                                        (4096, 1024, 1024, 0), (10240, 3072, 256, 256), (256 * 37, 1792, 128, 256)])
+                                        (4096, 1024, 1024, 0), (10240, 3072, 256, 256), (256 * 37, 1792, 128, 256),
+                                        (2048, 4096, 1024, 4256), (2048 + 17, 1024, 4096, 4256), (513, 3072, 128, 4256),
+                                        (300, 256, 192, 4256), (256 * 300 + 5, 512, 320, 4256), (65536, 1024, 1024, 4256)])
 def test_gemm_nt_plain(ops, dev, M, N, K, tile):
     x = rnd((M, K), dev, 1, dtype=BF16)
     w = rnd((N, K), dev, 2, 1.0 / math.sqrt(K), dtype=BF16)
@@ -65,7 +67,8 @@ def test_gemm_nt_layout_is_not_transposed(ops, dev):
     assert torch.equal(out.float(), (x.float() @ w.float().t()))
 
 
-@pytest.mark.parametrize("tile,M", [(128, 700), (256, 700), (1256, 700), (2256, 700), (256, 256 * 9)])
+@pytest.mark.parametrize("tile,M", [(128, 700), (256, 700), (1256, 700), (2256, 700), (256, 256 * 9), (4256, 700),
+                                    (4256, 256 * 9), (4256, 256 * 1100 + 3)])
 def test_gemm_nt_epilogues(ops, dev, tile, M):
     N, K = 1024, 1024
     x = rnd((M, K), dev, 3, dtype=BF16)

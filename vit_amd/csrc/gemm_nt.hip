@@ -13,7 +13,8 @@
 //     output columns of one output row.
 //   * launch-order block ids are remapped so that the blocks sharing an XCD walk neighbouring tiles.
 //
-// Two main loops:
+// Three main loops:
+//   quad  (256x256 tile, 4 waves of 128x128, persistent): the default for large problems; see the kernel.
 //   ring  (256x256 tile, 8 waves): K advances in 32-wide stages through a 5-slot LDS ring (5 x 32 KiB, the
 //         whole LDS of a CU).  Default form ("paired"): loads are issued for two stages at a time so that
 //         both 64-byte halves of every 128-byte line are requested back to back, one pair in flight while
@@ -471,6 +472,213 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
     else store_tile_wide<EPI, TM, false>(acc, ep, M, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "quad" loop: 256 x 256 tile, FOUR waves (2 x 2), each owning 128 x 128 of the output: 256 accumulator
+// registers per lane (the accumulation half of the register file at one wave per SIMD).  Compared with the
+// eight-wave ring a stage needs a third fewer LDS fragment reads per MFMA (16 reads feed 64 MFMAs), and every
+// wave carries a long, uniform instruction stream into which the next stage's fragment reads AND the global
+// loads of the stage four ahead are spread evenly (one load per eight MFMAs), so the load path never sees a
+// burst and the matrix pipe is never left waiting behind a queue of load issues.
+// Same LDS image as the ring (BK = 32 stages, 5 slots, chunk XOR, permuted weight rows); one barrier per stage:
+// at the top of stage kt the loads of kt+2 and kt+3 may still be in flight.
+// The kernel is persistent: one workgroup per CU walks tiles v, v + grid, ...  The LDS ring never drains between
+// tiles -- the last four stages of a tile issue the first four stages of the next one, so the only bubble at a
+// tile boundary is the epilogue itself, not a load round trip.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                           int M, int N, int K, int ldx, int ldw, EpiArgs ep) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor type exists for the device target only; the host pass needs just the stub
+    constexpr int BM = 256, BN = 256, BK = 32, NT = 256;
+    constexpr int TM = 8, TN = 8;                 // per wave: 128 (m) x 128 (n)
+    constexpr int OP_BYTES = 256 * BK * 2;        // 16 KiB per operand per stage
+    constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 32 KiB
+    constexpr int RING = 5, LPS = 8;              // loads per thread and stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = N / BN;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles = tiles_m * tiles_n;
+
+    // Sources are addressed through buffer descriptors: one per operand and tile (scalar registers, based at the
+    // tile's first row, sized to the rows that exist so that rows past M read as zero), a per-thread byte offset
+    // that is the same for every tile (1024 chunks per operand per stage, 4 per thread: chunk q -> row q>>2,
+    // slot q&3), and the stage's k offset as the scalar offset.
+    struct Tile {
+        int m0, n0;
+        __amdgpu_buffer_rsrc_t x, w;
+    };
+    auto set_tile = [&](int v, Tile& t) {
+        const int id = xcd_remap(v, tiles);
+        t.m0 = (id / tiles_n) * BM;
+        t.n0 = (id % tiles_n) * BN;
+        const int64_t xb = (int64_t)(M - t.m0) * ldx * 2, wb = (int64_t)(N - t.n0) * ldw * 2;
+        t.x = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (size_t)t.m0 * ldx), (short)0,
+                                                (int)(xb < 0x7fffffff ? xb : 0x7fffffff), 0x00020000);
+        t.w = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)t.n0 * ldw), (short)0,
+                                                (int)(wb < 0x7fffffff ? wb : 0x7fffffff), 0x00020000);
+    };
+    int xvo[4], wvo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = i * NT + tid, row = q >> 2, c = (q & 3) ^ (((row >> 3) & 1) * 3);
+        xvo[i] = (row * ldx + c * 8) * 2;
+        wvo[i] = (wide_wrow<EPI>(row) * ldw + c * 8) * 2;
+    }
+    // load i (0..7) of stage kt of tile t into ring slot `slot`: X chunks first, then W chunks
+    auto load_one = [&](const Tile& t, int kt, int slot, int i) {
+        char* base = smem + slot * STAGE_BYTES + (i >> 2) * OP_BYTES + ((i & 3) * NT + wave * 64) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((i >> 2) ? t.w : t.x, (lds_ptr_t)base, 16,
+                                                 (i >> 2) ? wvo[i & 3] : xvo[i & 3], kt * BK * 2, 0, 0);
+    };
+
+    const int frow = lane & 15;
+    const int foff = frow * 64 + (((lane >> 4) ^ (((frow >> 3) & 1) * 3)) << 4);
+    const int woff = wn * 128 * 64 + foff;
+    const int xoff = wm * 128 * 64 + foff;
+    bf16x8_t wf[2][TN];
+    bf16x8_t xf[TM];
+    auto frag_w = [&](int slot, int a) {
+        return *(const bf16x8_t*)(smem + slot * STAGE_BYTES + OP_BYTES + woff + a * 16 * 64);
+    };
+    auto frag_x = [&](int slot, int b) { return *(const bf16x8_t*)(smem + slot * STAGE_BYTES + xoff + b * 16 * 64); };
+
+    f32x4_t acc[2][4][TM];                        // [64-column half][16-column block][16-row block]
+
+    // The accumulators are pinned to the accumulation registers by issuing the MFMAs as volatile asm with an
+    // accumulation-register operand: left to the register allocator, a 256-register accumulator set is shuffled
+    // between the two register files inside the loop.  Volatile asm statements keep their order, and the empty
+    // memory-clobbering statements pin the loads between them, so the instruction stream is the written one:
+    // per 16-row block  4 MFMAs | W fragment read | 4 MFMAs | X fragment read + one global load.
+    auto mf = [](f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    };
+    auto mf_first = [](f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {   // first stage of a tile: C = A*B + 0
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    };
+#define VA_PIN asm volatile("" ::: "memory")
+    // One stage: 64 MFMAs; the next stage's fragments are read into the registers just retired and the eight
+    // loads of the stage four ahead (stage kt_load of tile `lt`) go out one per row block.
+    auto body = [&](auto parity, auto first, int next_slot, const Tile& lt, int kt_load, int load_slot) {
+        constexpr int P = decltype(parity)::value;
+        constexpr bool FIRST = decltype(first)::value;
+        auto block = [&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (FIRST) mf_first(acc[0][a][b], wf[P][a], xf[b]);
+                else mf(acc[0][a][b], wf[P][a], xf[b]);
+            }
+            VA_PIN;
+            if (DBG != 2) wf[P ^ 1][b] = frag_w(next_slot, b);
+            VA_PIN;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (FIRST) mf_first(acc[1][a][b], wf[P][4 + a], xf[b]);
+                else mf(acc[1][a][b], wf[P][4 + a], xf[b]);
+            }
+            VA_PIN;
+            if (DBG != 2) xf[b] = frag_x(next_slot, b);
+            if (DBG != 1) load_one(lt, kt_load, load_slot, b);
+            VA_PIN;
+        };
+        block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{});
+        block(std::integral_constant<int, 2>{}); block(std::integral_constant<int, 3>{});
+        block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{});
+        block(std::integral_constant<int, 6>{}); block(std::integral_constant<int, 7>{});
+    };
+#undef VA_PIN
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    const int nk = K / BK;   // even and >= 4 (checked by the host)
+    auto advance = [&](int sl) { return sl + 1 == RING ? 0 : sl + 1; };
+    auto before = [&](int sl) { return sl == 0 ? RING - 1 : sl - 1; };
+
+    int v = blockIdx.x;
+    Tile cur;
+    set_tile(v, cur);
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) load_one(cur, st, st, i);
+    wait_vm<3 * LPS>();                                   // stage 0 landed (own loads) ...
+    __builtin_amdgcn_s_barrier();                          // ... and everybody else's
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) xf[b] = frag_x(0, b);
+
+    // Top of a stage: the loads of the next three stages are outstanding; waiting down to two stages retires the
+    // next one (read by this stage's prefetch) and the barrier tells that every wave has taken the current stage
+    // into registers and is done with the previous one, whose slot the stage four ahead refills during this body.
+    int slot = 0;                                          // ring slot of the current stage
+    uint64_t t_sync = 0, t_body = 0, t_last = 0;          // DBG 5: cycles in waits+barriers / in stage bodies
+    // `relaxed`: the first three stages after the epilogue of a tile whose rows all exist.  Memory operations
+    // retire in issue order and the loads of this tile's stages 1..3 went out before the epilogue's stores, so the
+    // loads a stage needs are followed by two stages' loads AND those stores (32 instructions per wave for one
+    // 2-byte output, 64 otherwise): that many may stay in flight, and the stores need not drain before the matrix
+    // work resumes.  (An edge tile skips the stores of missing row blocks, so it gets the plain count.)
+    constexpr int STORES = (EPI == VA_EPI_BF16 || EPI == VA_EPI_GELU_BWD) ? 32 : 64;
+    constexpr int RELAXED = 2 * LPS + STORES < 63 ? 2 * LPS + STORES : 63;
+    auto sync = [&](bool relaxed) {
+        if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_body += now - t_last; t_last = now; }
+        if (relaxed) wait_vm<RELAXED>();
+        else wait_vm<2 * LPS>();
+        if (DBG != 3) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_sync += now - t_last; t_last = now; }
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    if (DBG == 5) t_last = __builtin_amdgcn_s_memtime();
+    bool after_epilogue = false;
+    for (; v < tiles; v += gridDim.x) {
+        // the tile whose first four stages ride in this tile's last four bodies; after the last tile the same
+        // loads are issued once more (valid addresses, never read) so that the counted waits stay uniform
+        Tile nxt;
+        set_tile(v + (int)gridDim.x < tiles ? v + (int)gridDim.x : v, nxt);
+        // stage kt issues the loads of stage kt+4: of this tile, or of the next one from its stage 0 on
+        auto stage_one = [&](auto parity, auto first, int kt, bool relaxed) {
+            const bool in_cur = kt + 4 < nk;
+            sync(relaxed);
+            body(parity, first, advance(slot), in_cur ? cur : nxt, in_cur ? kt + 4 : kt + 4 - nk, before(slot));
+            slot = advance(slot);
+        };
+        stage_one(P0{}, Yes{}, 0, after_epilogue);
+        stage_one(P1{}, No{}, 1, after_epilogue);
+        stage_one(P0{}, No{}, 2, after_epilogue);
+        stage_one(P1{}, No{}, 3, false);
+        for (int kt = 4; kt < nk; kt += 2) {
+            stage_one(P0{}, No{}, kt, false);
+            stage_one(P1{}, No{}, kt + 1, false);
+        }
+
+        // the asm MFMAs are opaque to the compiler's hazard tracking: let the last results retire before they are read
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        const bool full = cur.m0 + wm * 128 + 128 <= M;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if (full) store_tile_wide<EPI, TM, true>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
+            else store_tile_wide<EPI, TM, false>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
+        }
+        cur = nxt;
+        after_epilogue = full;
+    }
+    wait_vm0();   // the trailing loads must not land in LDS after the workgroup has gone
+    if (DBG == 5 && lane == 0) {
+        float* o = (float*)ep.out + ((size_t)blockIdx.x * 4 + wave) * 4;
+        const uint64_t now = __builtin_amdgcn_s_memtime();
+        o[0] = (float)t_sync; o[1] = (float)t_body; o[2] = (float)(now - t_last);
+    }
+#endif
+}
+
 int ensure_lds(const void* kern, int bytes, bool* flags) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -510,11 +718,39 @@ int launch_ring(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
     return VA_OK;
 }
 
+template <int EPI, int DBG = 0>
+int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
+                hipStream_t stream) {
+    constexpr int LDS = 5 * 2 * 256 * 32 * 2;
+    auto kern = gemm_nt_quad_kernel<EPI, DBG>;
+    static bool flags[64] = {};
+    if (int e = ensure_lds((const void*)kern, LDS, flags)) return e;
+    const int tiles = ((M + 255) / 256) * (N / 256);
+    static int cus[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && cus[dev] == 0) {
+        if (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] <= 0)
+            cus[dev] = 256;
+    }
+    const int grid = tiles < cus[dev & 63] ? tiles : cus[dev & 63];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, X, W, M, N, K, ldx, ldw, ep);
+    VA_CHECK_LAUNCH("va_gemm_nt");
+    return VA_OK;
+}
+
 template <int EPI>
 int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
                hipStream_t stream) {
     if (tile == 256) return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
     if (tile == 2256) return launch_ring<EPI, false>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (tile == 4256) return launch_quad<EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
+#ifdef VA_GEMM_DEBUG_VARIANTS   // timing experiments only (results are wrong): no loads / no fragment reads / no barrier
+    if (EPI == VA_EPI_BF16 && tile == 4257) return launch_quad<VA_EPI_BF16, 1>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4258) return launch_quad<VA_EPI_BF16, 2>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4259) return launch_quad<VA_EPI_BF16, 3>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4261) return launch_quad<VA_EPI_BF16, 5>(X, W, M, N, K, ldx, ldw, ep, stream);
+#endif
     if (tile == 1256) return launch_pair<256, 256, 2, 4, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
     return launch_pair<128, 128, 2, 2, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
 }
@@ -533,8 +769,8 @@ extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, in
     VA_CHECK_ARG(ldx % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "va_gemm_nt: leading dimensions must keep 16-byte alignment");
     VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) % 16 == 0, "va_gemm_nt: operands must be 16-byte aligned");
     VA_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "va_gemm_nt: problem too large");
-    if (tile == 0) tile = (N % 256 == 0 && M >= 2048 && K >= 128) ? 256 : 128;
-    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256) && N % 256 == 0 && K >= 128),
+    if (tile == 0) tile = (N % 256 == 0 && M >= 2048 && K >= 128) ? 4256 : 128;
+    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || (tile >= 4256 && tile <= 4261)) && N % 256 == 0 && K >= 128),
                  "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc};
     const bf16_t* X = (const bf16_t*)x;
