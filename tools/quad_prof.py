@@ -16,5 +16,5 @@ for name, (Nn, K) in {"qkv": (3 * D, D), "fc2": (D, 4 * D)}.items():
     f = out.view(torch.float32).flatten()[:256 * 16].reshape(256, 4, 4).cpu()
     tiles = (M // 256) * (Nn // 256); stages = tiles / 256 * (K // 32)
     print(f"{name}: {ms:.3f} ms; per stage: sync {f[:, :, 0].mean() / stages:.0f}  body {f[:, :, 1].mean() / stages:.0f} cycles; "
-          f"epilogue+rest per tile {f[:, :, 2].mean():.0f}; total counted {(f[:, :, 0] + f[:, :, 1]).mean():.0f} cycles "
+          f"epilogue per tile {f[:, :, 3].mean() / (tiles / 256):.0f}; tail {f[:, :, 2].mean():.0f}; total counted {(f[:, :, 0] + f[:, :, 1]).mean():.0f} cycles "
           f"-> {(f[:, :, 0] + f[:, :, 1]).mean() / ms / 1e6:.2f} GHz-equivalent")

@@ -102,7 +102,9 @@ VA_DEVINL int wide_wrow(int row) {
 // bytes per output row.
 // FULL_M: all of the wave's rows exist, so the row loop carries no branches (a skipped row block would make
 // the compiler drain the memory counter in front of every later block's stores).
-template <int EPI, int TM, bool FULL_M = false>
+// HAS_BIAS = false: the caller knows there is no bias and the adds are left out (with a run-time test inside, the add
+// would become an add plus a select on every accumulator value); true: a null bias pointer adds zeros.
+template <int EPI, int TM, bool FULL_M = false, bool HAS_BIAS = true>
 VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
     const int ldc = ep.ldc;
     const int g = lane >> 4;
@@ -111,7 +113,7 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
     float bias[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) bias[j] = 0.f;
-    if (EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
+    if (HAS_BIAS && EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) *(f32x4_t*)(bias + 4 * a) = *(const f32x4_t*)(ep.bias + col(a));
     }
@@ -124,7 +126,7 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * a + j] = acc[a][b][j] + bias[4 * a + j];
+            for (int j = 0; j < 4; ++j) v[4 * a + j] = HAS_BIAS ? acc[a][b][j] + bias[4 * a + j] : acc[a][b][j];
         if (EPI == VA_EPI_BF16) {
             u32x4_t lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             u32x4_t hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
 // tiles -- the last four stages of a tile issue the first four stages of the next one, so the only bubble at a
 // tile boundary is the epilogue itself, not a load round trip.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, int DBG = 0>
+template <int EPI, bool HAS_BIAS, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                            int M, int N, int K, int ldx, int ldw, EpiArgs ep) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor type exists for the device target only; the host pass needs just the stub
@@ -664,8 +666,8 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         const bool full = cur.m0 + wm * 128 + 128 <= M;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            if (full) store_tile_wide<EPI, TM, true>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
-            else store_tile_wide<EPI, TM, false>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
+            if (full) store_tile_wide<EPI, TM, true, HAS_BIAS>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
+            else store_tile_wide<EPI, TM, false, HAS_BIAS>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
         }
         cur = nxt;
         after_epilogue = full;
@@ -718,11 +720,11 @@ int launch_ring(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
     return VA_OK;
 }
 
-template <int EPI, int DBG = 0>
+template <int EPI, bool HAS_BIAS, int DBG = 0>
 int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
                 hipStream_t stream) {
     constexpr int LDS = 5 * 2 * 256 * 32 * 2;
-    auto kern = gemm_nt_quad_kernel<EPI, DBG>;
+    auto kern = gemm_nt_quad_kernel<EPI, HAS_BIAS, DBG>;
     static bool flags[64] = {};
     if (int e = ensure_lds((const void*)kern, LDS, flags)) return e;
     const int tiles = ((M + 255) / 256) * (N / 256);
@@ -744,12 +746,16 @@ int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, 
                hipStream_t stream) {
     if (tile == 256) return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
     if (tile == 2256) return launch_ring<EPI, false>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (tile == 4256) return launch_quad<EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (tile == 4256) {   // the bias adds are compiled in only where a bias can be present
+        if (EPI == VA_EPI_BIAS_GELU || (EPI != VA_EPI_GELU_BWD && ep.bias != nullptr))
+            return launch_quad<EPI, EPI != VA_EPI_GELU_BWD>(X, W, M, N, K, ldx, ldw, ep, stream);
+        return launch_quad<EPI, EPI == VA_EPI_BIAS_GELU>(X, W, M, N, K, ldx, ldw, ep, stream);
+    }
 #ifdef VA_GEMM_DEBUG_VARIANTS   // timing experiments only (results are wrong): no loads / no fragment reads / no barrier
-    if (EPI == VA_EPI_BF16 && tile == 4257) return launch_quad<VA_EPI_BF16, 1>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (EPI == VA_EPI_BF16 && tile == 4258) return launch_quad<VA_EPI_BF16, 2>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (EPI == VA_EPI_BF16 && tile == 4259) return launch_quad<VA_EPI_BF16, 3>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (EPI == VA_EPI_BF16 && tile == 4261) return launch_quad<VA_EPI_BF16, 5>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4257) return launch_quad<VA_EPI_BF16, false, 1>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4258) return launch_quad<VA_EPI_BF16, false, 2>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4259) return launch_quad<VA_EPI_BF16, false, 3>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4261) return launch_quad<VA_EPI_BF16, false, 5>(X, W, M, N, K, ldx, ldw, ep, stream);
 #endif
     if (tile == 1256) return launch_pair<256, 256, 2, 4, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
     return launch_pair<128, 128, 2, 2, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
