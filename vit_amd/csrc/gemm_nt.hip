@@ -775,7 +775,15 @@ extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, in
     VA_CHECK_ARG(ldx % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "va_gemm_nt: leading dimensions must keep 16-byte alignment");
     VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) % 16 == 0, "va_gemm_nt: operands must be 16-byte aligned");
     VA_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "va_gemm_nt: problem too large");
-    if (tile == 0) tile = (N % 256 == 0 && M >= 2048 && K >= 128) ? 4256 : 128;
+    if (tile == 0) {
+        // Large problems: the four-wave persistent kernel where the epilogue is light relative to the K loop (plain
+        // 2-byte output; f32 output at long K).  With one wave per SIMD nothing overlaps an epilogue's loads and
+        // transcendental math, so the GELU epilogues and the short-K f32+residual GEMM stay on the eight-wave ring,
+        // whose two waves per SIMD cover each other's stalls.
+        const bool big = N % 256 == 0 && M >= 2048 && K >= 128;
+        const bool quad = epilogue == VA_EPI_BF16 || (epilogue == VA_EPI_F32 && K >= 2048);
+        tile = !big ? 128 : quad ? 4256 : 256;
+    }
     VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || (tile >= 4256 && tile <= 4261)) && N % 256 == 0 && K >= 128),
                  "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc};
