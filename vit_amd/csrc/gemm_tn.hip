@@ -181,11 +181,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// Large-problem variant: 256(n) x 256(k) tile, 8 waves (2 x 4, each 128 x 64 as 4 x 2 MFMA 32x32x16 tiles),
-// contraction in 32-row stages through a 5-slot LDS ring (all 160 KiB) with counted vmcnt waits, and MFMA
-// fragments read from LDS one k-step ahead of their use (see gemm_nt.hip, ring loop, for the protocol).
-// Rows of a staged tile are 512 B (32 chunks); chunk XOR ((row&3)<<2) keeps the transposed reads
-// conflict-free.  One workgroup per CU, so the grid is sized to about one workgroup per CU by the M split.
+// Large-problem variant: 256(n) x 256(k) tile, 8 waves (2 x 4, each 128 x 64 as 8 x 4 MFMA 16x16x32 tiles: under
+// the chip's clock management this shape sustains about 1.12 x the rate of 32x32x16 at equal cycles per FLOP),
+// contraction in 32-row stages (one MFMA k-step) through a 5-slot LDS ring (all 160 KiB) with counted vmcnt
+// waits, and MFMA fragments read from LDS one stage ahead of their use (see gemm_nt.hip, ring loop, for the
+// protocol).  Rows of a staged tile are 512 B (32 chunks); the chunk index is XORed with ((row&3)<<2) and with
+// ((row>>3)&1)<<1, which keeps the 16 rows a transposed read touches (4 per 16-lane group) on distinct banks.
+// One workgroup per CU, so the grid is sized to about one workgroup per CU by the M split.
 // ------------------------------------------------------------------------------------------------
 constexpr int RBM = 32;                       // contraction rows per stage
 constexpr int ROP_BYTES = RBM * 256 * 2;      // 16 KiB per operand per stage
@@ -222,7 +224,7 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
     for (int i = 0; i < 2; ++i) {
         const int q = i * 512 + tid;
         srow[i] = q >> 5;
-        scol[i] = ((q & 31) ^ ((srow[i] & 3) << 2)) * 8;
+        scol[i] = ((q & 31) ^ ((srow[i] & 3) << 2) ^ (((srow[i] >> 3) & 1) << 1)) * 8;
     }
     auto stage = [&](int kt, int slot) {
         char* yb = smem + slot * RSTAGE_BYTES;
@@ -237,38 +239,42 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
         }
     };
 
-    f32x16_t acc[4][2];
+    // D[n][k]: dY^T is the A operand, X the B operand: lane holds rows n = 4*(lane>>4) + j, column k = lane & 15
+    f32x4_t acc[8][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     constexpr bool do_bias = DO_BIAS;
-    f32x16_t bacc;                  // wave (wn, wk) sums the 32 columns of n-block a = wk
-#pragma unroll
-    for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+    f32x4_t bacc[2];                // wave (wn, wk) sums the columns of n-blocks a = 2*wk, 2*wk + 1
+    bacc[0] = bacc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
-    const int gi = lane >> 4, cg = gi & 1, h = gi >> 1, q4 = (lane & 15) >> 2, p = lane & 3;
+    // A 16x16x32 operand fragment: lane l holds 8 consecutive m (k-group l>>4) of column l & 15.  Its 16-lane group
+    // reads rows 8*(l>>4) .. +3 (second read: +4) of 16 columns; lane 4q+p of the group addresses row q, columns
+    // 4p .. 4p+3.
+    const int gi = lane >> 4, q4 = (lane & 15) >> 2, p = lane & 3;
     auto tr_off = [&](int colbase) {
-        const int row = 8 * h + q4;
-        const int chunk = ((colbase + 16 * cg + 4 * p) >> 3) ^ ((row & 3) << 2);
+        const int row = 8 * gi + q4;
+        const int chunk = ((colbase + 4 * p) >> 3) ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 1);
         return row * 512 + (chunk << 4) + (p & 1) * 8;
     };
-    int yoff[4], xoff[2];
+    int yoff[8], xoff[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) yoff[a] = tr_off(wn * 128 + a * 32);
+    for (int a = 0; a < 8; ++a) yoff[a] = tr_off(wn * 128 + a * 16);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) xoff[b] = ROP_BYTES + tr_off(wk * 64 + b * 32);
+    for (int b = 0; b < 4; ++b) xoff[b] = ROP_BYTES + tr_off(wk * 64 + b * 16);
 
-    // fragments of k-step s (16 rows) of the stage in `slot`
-    auto frag = [&](int slot, int s, int off) {
-        const char* ptr = smem + slot * RSTAGE_BYTES + off + s * 16 * 512;
+    // fragment of the stage in `slot`
+    auto frag = [&](int slot, int off) {
+        const char* ptr = smem + slot * RSTAGE_BYTES + off;
         return join_tr(lds_read_tr16(ptr), lds_read_tr16(ptr + 4 * 512));
     };
-    bf16x8_t fa[2][4], fb[2][2];
+    bf16x8_t fa[8], fb[4], fbn[4];
+    int ymine[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) ymine[jj] = tr_off(wn * 128 + (2 * wk + jj) * 16);
 
     // zero rows [valid, 32) of both operand tiles of a slot (ragged end of M)
     auto zero_tail = [&](int slot, int valid) {
@@ -279,41 +285,41 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
         }
     };
 
-    // one k-step: 8 MFMAs on fragment set S while the next k-step's fragments land in set S^1
-    auto kstep = [&](auto set, auto prefetch, int nslot, int ns, bool bias_now) {
-        constexpr int S = decltype(set)::value;
+    // one stage: 32 MFMAs; after the four MFMAs of n-block a the next stage's dY fragment a replaces the retired
+    // one and (a < 4) X fragment a of the next stage is read into the spare set
+    auto kstep = [&](auto prefetch, int cur_slot, int nslot, bool bias_now) {
         constexpr bool PREFETCH = decltype(prefetch)::value;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(fa[S][a], fb[S][b], acc[a][b]);
-            if (PREFETCH) {
-                fa[S ^ 1][a] = frag(nslot, ns, yoff[a]);
-                if (a < 2) fb[S ^ 1][a] = frag(nslot, ns, xoff[a]);
-            }
+        if (DO_BIAS && bias_now) {
+            // uniform branch: this workgroup's share of the M stages.  The wave's two n-blocks are a run-time choice
+            // (by wave index), so their fragments are read again from the stage's slot rather than selected out of
+            // the register set with 24 conditional moves.
+            const bf16x8_t m0 = frag(cur_slot, ymine[0]), m1 = frag(cur_slot, ymine[1]);
+            bacc[0] = mfma16(m0, ones, bacc[0]);
+            bacc[1] = mfma16(m1, ones, bacc[1]);
         }
-        if (DO_BIAS && bias_now) {   // uniform branch: this workgroup's share of the M stages
-            const u32x4_t f0 = __builtin_bit_cast(u32x4_t, fa[S][0]), f1 = __builtin_bit_cast(u32x4_t, fa[S][1]);
-            const u32x4_t f2 = __builtin_bit_cast(u32x4_t, fa[S][2]), f3 = __builtin_bit_cast(u32x4_t, fa[S][3]);
-            u32x4_t mine;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mine[j] = wk == 0 ? f0[j] : (wk == 1 ? f1[j] : (wk == 2 ? f2[j] : f3[j]));
-            bacc = mfma32(__builtin_bit_cast(bf16x8_t, mine), ones, bacc);
+        for (int a = 0; a < 8; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+            if (PREFETCH) {
+                fa[a] = frag(nslot, yoff[a]);
+                if (a < 4) fbn[a] = frag(nslot, xoff[a]);
+            }
         }
         if (PREFETCH) {
 #define VA_GRP(n_reads)                                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       \
     __builtin_amdgcn_sched_group_barrier(0x100, n_reads, 0);
-            VA_GRP(4) VA_GRP(4) VA_GRP(2) VA_GRP(2)
+            VA_GRP(4) VA_GRP(4) VA_GRP(4) VA_GRP(4) VA_GRP(2) VA_GRP(2) VA_GRP(2) VA_GRP(2)
 #undef VA_GRP
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = fbn[b];
         }
     };
     // the bias column sums are spread over the k-tile workgroups of an output row: each takes every
     // tiles_k-th stage, so no workgroup carries more than 1/tiles_k of the extra MFMAs
     const int my_ktile = id % tiles_k;
     auto bias_stage = [&](int stage_idx) { return DO_BIAS && (stage_idx % tiles_k) == my_ktile; };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
     auto advance = [&](int sl) { return sl + 1 == RRING ? 0 : sl + 1; };
@@ -326,9 +332,9 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int a = 0; a < 4; ++a) fa[0][a] = frag(0, 0, yoff[a]);
+    for (int a = 0; a < 8; ++a) fa[a] = frag(0, yoff[a]);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) fb[0][b] = frag(0, 0, xoff[b]);
+    for (int b = 0; b < 4; ++b) fb[b] = frag(0, xoff[b]);
 
     int slot = 0;
     int kt = 0;
@@ -337,22 +343,19 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stage(kt + 4, slot == 0 ? RRING - 1 : slot - 1);
-        kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
-        kstep(S1{}, Yes{}, advance(slot), 0, bias_stage(kt));
+        kstep(Yes{}, slot, advance(slot), bias_stage(kt));
         slot = advance(slot);
     }
     // tail: stages nk-4 .. nk-1
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
-    kstep(S1{}, Yes{}, advance(slot), 0, bias_stage(kt));
+    kstep(Yes{}, slot, advance(slot), bias_stage(kt));
     slot = advance(slot); ++kt;
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
-    kstep(S1{}, Yes{}, advance(slot), 0, bias_stage(kt));
+    kstep(Yes{}, slot, advance(slot), bias_stage(kt));
     slot = advance(slot); ++kt;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -361,24 +364,26 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
         zero_tail(advance(slot), tail_valid);
         __syncthreads();
     }
-    kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
-    kstep(S1{}, Yes{}, advance(slot), 0, bias_stage(kt));
+    kstep(Yes{}, slot, advance(slot), bias_stage(kt));
     slot = advance(slot); ++kt;
-    kstep(S0{}, Yes{}, slot, 1, bias_stage(kt));
-    kstep(S1{}, No{}, 0, 0, bias_stage(kt));
+    kstep(No{}, slot, 0, bias_stage(kt));
 
-    const int hh = lane >> 5, col = lane & 31;
+    // one accumulator register across the wave: four 64-byte row segments of dW
+    const int rg = lane >> 4, col = lane & 15;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float* base = DW + (size_t)(n0 + wn * 128 + a * 32) * lddw + k0 + wk * 64 + b * 32 + col;
+        for (int b = 0; b < 4; ++b) {
+            float* base = DW + (size_t)(n0 + wn * 128 + a * 16 + 4 * rg) * lddw + k0 + wk * 64 + b * 16 + col;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) unsafeAtomicAdd(base + (size_t)acc32_row(i, hh) * lddw, acc[a][b][i]);
+            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(base + (size_t)j * lddw, acc[a][b][j]);
         }
-    if (do_bias && col == 0) {
+    if (do_bias && col == 0) {   // every column of bacc holds the same sums: lane column 0 publishes them
 #pragma unroll
-        for (int i = 0; i < 16; ++i) unsafeAtomicAdd(DBIAS + n0 + wn * 128 + wk * 32 + acc32_row(i, hh), bacc[i]);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                unsafeAtomicAdd(DBIAS + n0 + wn * 128 + (2 * wk + jj) * 16 + 4 * rg + j, bacc[jj][j]);
     }
 }
 
