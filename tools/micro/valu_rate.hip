@@ -23,6 +23,13 @@ __global__ __launch_bounds__(512) void k(uint32_t* __restrict__ out, uint32_t se
                 if (OP == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
                 if (OP == 7) asm volatile("v_xad_u32 %0, %0, %1, %0" : "+v"(x[i]) : "v"(c));
                 if (OP == 8) asm volatile("v_lshrrev_b32 %0, 15, %0" : "+v"(x[i]));
+                if (OP == 10) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[i]) : "v"(c));
+                if (OP == 11) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+                if (OP == 12) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
+                if (OP == 13 && (i & 1) == 0) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(*(uint64_t*)&x[i]) : "v"(*(uint64_t*)&x[0]));
+                if (OP == 14 && (i & 1) == 0) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(uint64_t*)&x[i]) : "v"(*(uint64_t*)&x[0]));
+                if (OP == 15) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(c) : "vcc");
+                if (OP == 16) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
                 if (OP == 9) asm volatile("v_cmp_ge_u16_sdwa vcc, %0, %1 src0_sel:WORD_1 src1_sel:WORD_0\n v_cndmask_b32 %0, 0, %0, vcc" : "+v"(x[i]) : "v"(c) : "vcc");
             }
     }
@@ -59,5 +66,12 @@ int main() {
     run<8>("v_lshrrev_b32", out, 1);
     run<6>("v_exp_f32", out, 1);
     run<9>("v_cmp_u16_sdwa+v_cndmask", out, 2);
+    run<10>("v_fma_f32", out, 1);
+    run<11>("v_mul_f32", out, 1);
+    run<12>("v_rcp_f32", out, 1);
+    run<13>("v_pk_fma_f32 (per instr, 2 elems; half as many issued)", out, 1);
+    run<14>("v_pk_mul_f32 (per instr, 2 elems; half as many issued)", out, 1);
+    run<15>("v_cndmask_b32", out, 1);
+    run<16>("v_cvt_pk_bf16_f32", out, 1);
     return 0;
 }
