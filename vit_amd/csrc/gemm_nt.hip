@@ -746,10 +746,11 @@ int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, 
                hipStream_t stream) {
     if (tile == 256) return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
     if (tile == 2256) return launch_ring<EPI, false>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (tile == 4256) {   // the bias adds are compiled in only where a bias can be present
-        if (EPI == VA_EPI_BIAS_GELU || (EPI != VA_EPI_GELU_BWD && ep.bias != nullptr))
-            return launch_quad<EPI, EPI != VA_EPI_GELU_BWD>(X, W, M, N, K, ldx, ldw, ep, stream);
-        return launch_quad<EPI, EPI == VA_EPI_BIAS_GELU>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (tile == 4256) {
+        // The bias adds are compiled out only for the plain 2-byte output without a bias (the f32 epilogue keeps
+        // them: its bias-free build schedules worse and measures slower than adding zeros).
+        if (EPI == VA_EPI_BF16 && ep.bias == nullptr) return launch_quad<EPI, EPI != VA_EPI_BF16>(X, W, M, N, K, ldx, ldw, ep, stream);
+        return launch_quad<EPI, EPI != VA_EPI_GELU_BWD>(X, W, M, N, K, ldx, ldw, ep, stream);
     }
 #ifdef VA_GEMM_DEBUG_VARIANTS   // timing experiments only (results are wrong): no loads / no fragment reads / no barrier
     if (EPI == VA_EPI_BF16 && tile == 4257) return launch_quad<VA_EPI_BF16, false, 1>(X, W, M, N, K, ldx, ldw, ep, stream);
@@ -776,12 +777,11 @@ extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, in
     VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) % 16 == 0, "va_gemm_nt: operands must be 16-byte aligned");
     VA_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "va_gemm_nt: problem too large");
     if (tile == 0) {
-        // Large problems: the four-wave persistent kernel where the epilogue is light relative to the K loop (plain
-        // 2-byte output; f32 output at long K).  With one wave per SIMD nothing overlaps an epilogue's loads and
-        // transcendental math, so the GELU epilogues and the short-K f32+residual GEMM stay on the eight-wave ring,
-        // whose two waves per SIMD cover each other's stalls.
+        // Large problems: the four-wave persistent kernel for the plain 2-byte and the f32 outputs.  With one wave
+        // per SIMD nothing overlaps an epilogue's transcendental math, so the GELU epilogues stay on the eight-wave
+        // ring, whose two waves per SIMD cover each other's stalls.
         const bool big = N % 256 == 0 && M >= 2048 && K >= 128;
-        const bool quad = epilogue == VA_EPI_BF16 || (epilogue == VA_EPI_F32 && K >= 2048);
+        const bool quad = epilogue == VA_EPI_BF16 || epilogue == VA_EPI_F32;
         tile = !big ? 128 : quad ? 4256 : 256;
     }
     VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || (tile >= 4256 && tile <= 4261)) && N % 256 == 0 && K >= 128),
