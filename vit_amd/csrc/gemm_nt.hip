@@ -104,7 +104,11 @@ VA_DEVINL int wide_wrow(int row) {
 // the compiler drain the memory counter in front of every later block's stores).
 // HAS_BIAS = false: the caller knows there is no bias and the adds are left out (with a run-time test inside, the add
 // would become an add plus a select on every accumulator value); true: a null bias pointer adds zeros.
-template <int EPI, int TM, bool FULL_M = false, bool HAS_BIAS = true>
+// RESID_AHEAD (f32 epilogue, all rows present): the wave's whole residual block is requested before the first row
+// block is processed, instead of four loads in front of each row block's stores (the compiler may not move loads
+// of `resid` above stores to `out` on its own).  Safe for out == resid: a lane reads exactly the elements it later
+// writes.  Costs 4*TM*4 registers: for the kernel whose accumulators live in the accumulation registers.
+template <int EPI, int TM, bool FULL_M = false, bool HAS_BIAS = true, bool RESID_AHEAD = false>
 VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
     const int ldc = ep.ldc;
     const int g = lane >> 4;
@@ -116,6 +120,15 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
     if (HAS_BIAS && EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) *(f32x4_t*)(bias + 4 * a) = *(const f32x4_t*)(ep.bias + col(a));
+    }
+    constexpr bool AHEAD = RESID_AHEAD && FULL_M && EPI == VA_EPI_F32;
+    f32x4_t ahead[AHEAD ? TM : 1][4];
+    if (AHEAD && ep.resid != nullptr) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                ahead[AHEAD ? b : 0][a] = *(const f32x4_t*)(ep.resid + (size_t)(m_wave + b * 16 + (lane & 15)) * ldc + col(a));
     }
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
@@ -148,7 +161,7 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
             if (ep.resid != nullptr) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const f32x4_t rv = *(const f32x4_t*)(ep.resid + (size_t)m * ldc + col(a));
+                    const f32x4_t rv = AHEAD ? ahead[AHEAD ? b : 0][a] : *(const f32x4_t*)(ep.resid + (size_t)m * ldc + col(a));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[4 * a + j] += rv[j];
                 }
@@ -666,7 +679,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         const bool full = cur.m0 + wm * 128 + 128 <= M;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            if (full) store_tile_wide<EPI, TM, true, HAS_BIAS>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
+            if (full) store_tile_wide<EPI, TM, true, HAS_BIAS, true>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
             else store_tile_wide<EPI, TM, false, HAS_BIAS>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
         }
         cur = nxt;
