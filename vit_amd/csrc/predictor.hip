@@ -160,6 +160,87 @@ __global__ __launch_bounds__(256) void dwconv_silu_kernel(const float* __restric
     }
 }
 
+// The same for rows of C = 256 * NCH channels (NCH <= 8): one wave per RUN consecutive time steps of one batch
+// item.  The inputs of a run are read once into a sliding window (RUN + 3 rows instead of 4 * RUN), and a row's
+// results stay in registers until its norm is known, so the normalised form needs no second pass over the output.
+template <int NCH, int RUN>
+__global__ __launch_bounds__(256) void dwconv_silu_run_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                              const float* __restrict__ BIAS, float* __restrict__ OUT,
+                                                              int64_t runs, int L, int normalize) {
+    constexpr int C = 256 * NCH;
+    const int lane = threadIdx.x & 63;
+    const int64_t run = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (run >= runs) return;
+    const int runs_per_seq = (L + RUN - 1) / RUN;
+    const int64_t b = run / runs_per_seq;
+    const int t0 = (int)(run % runs_per_seq) * RUN;
+    const float* xb = X + b * (int64_t)L * C;
+    float* ob = OUT + b * (int64_t)L * C;
+    f32x4_t res[RUN][NCH];
+    float ss[RUN];
+#pragma unroll
+    for (int r = 0; r < RUN; ++r) ss[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const int c0 = lane * 4 + 256 * m;
+        const f32x4_t bias = *(const f32x4_t*)(BIAS + c0);
+        f32x4_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = *(const f32x4_t*)(W + (int64_t)(c0 + e) * 4);   // taps of channel c0+e
+        f32x4_t win[RUN + 3];                        // rows t0-3 .. t0+RUN-1 (zeros before the sequence start)
+#pragma unroll
+        for (int i = 0; i < RUN + 3; ++i) {
+            const int t = t0 - 3 + i;
+            win[i] = (t >= 0 && t < L) ? *(const f32x4_t*)(xb + (int64_t)t * C + c0) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < RUN; ++r) {
+            f32x4_t acc = bias;
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {      // tap i multiplies x[t - 3 + i]; same order as the one-row kernel
+                if (t0 + r - (3 - tap) < 0) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(w[e][tap], win[r + tap][e], acc[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] = acc[e] / (1.0f + __expf(-acc[e]));     // SiLU
+                ss[r] = fmaf(acc[e], acc[e], ss[r]);
+            }
+            res[r][m] = acc;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RUN; ++r) {
+        if (t0 + r >= L) break;
+        float inv = 1.0f;
+        if (normalize) {
+            float tot = ss[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+            inv = 1.0f / fmaxf(sqrtf(tot), 1e-12f);   // F.normalize: x / max(||x||, eps)
+        }
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            f32x4_t v = res[r][m];
+            if (normalize) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= inv;
+            }
+            *(f32x4_t*)(ob + (int64_t)(t0 + r) * C + lane * 4 + 256 * m) = v;
+        }
+    }
+}
+
+template <int NCH>
+void launch_dwconv_run(const float* x, const float* w, const float* bias, float* out, int64_t B, int L, int normalize,
+                       hipStream_t stream) {
+    constexpr int RUN = NCH <= 2 ? 8 : 4;
+    const int64_t runs = B * ((L + RUN - 1) / RUN);
+    hipLaunchKernelGGL((dwconv_silu_run_kernel<NCH, RUN>), dim3((unsigned)((runs + 3) / 4)), dim3(256), 0, stream, x, w,
+                       bias, out, runs, L, normalize);
+}
+
 }  // namespace
 
 extern "C" int va_gated_delta_seq(const float* q, const float* k, const float* v, const float* alpha, const float* beta,
@@ -191,8 +272,15 @@ extern "C" int va_dwconv1d_causal_silu(const float* x, const float* w, const flo
                  "va_dwconv1d_causal_silu: misaligned operand");
     const int64_t rows = B * L;
     VA_CHECK_ARG(rows < (1ll << 33) && L < (1ll << 31) && C < (1ll << 31), "va_dwconv1d_causal_silu: problem too large");
-    hipLaunchKernelGGL(dwconv_silu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, bias, out, rows,
-                       (int)L, (int)C, normalize);
+    switch (C % 256 == 0 ? C / 256 : 0) {   // whole multiples of 256 channels up to 2048: the sliding-window kernel
+        case 1: launch_dwconv_run<1>(x, w, bias, out, B, (int)L, normalize, stream); break;
+        case 2: launch_dwconv_run<2>(x, w, bias, out, B, (int)L, normalize, stream); break;
+        case 4: launch_dwconv_run<4>(x, w, bias, out, B, (int)L, normalize, stream); break;
+        case 8: launch_dwconv_run<8>(x, w, bias, out, B, (int)L, normalize, stream); break;
+        default:
+            hipLaunchKernelGGL(dwconv_silu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, w, bias, out,
+                               rows, (int)L, (int)C, normalize);
+    }
     VA_CHECK_LAUNCH("va_dwconv1d_causal_silu");
     return VA_OK;
 }
