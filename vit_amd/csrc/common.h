@@ -79,25 +79,28 @@ VA_DEVINL int acc32_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 // v_rcp_f32, one v_exp_f32 and five FMAs instead of the branchy library erff, because the GEMM epilogues
 // that call this run on a CU whose matrix pipe idles meanwhile.  exp(-x^2/2) is shared between the
 // normal CDF and the normal PDF of the derivative.
-VA_DEVINL void gelu_parts(float x, float& cdf, float& gauss) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    gauss = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);            // exp(-x^2/2)
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float half_erfc = 0.5f * poly * t * gauss;                          // 0.5 * erfc(|x|/sqrt2)
-    cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+// half_erfc(|x|/sqrt2) and exp(-x^2/2) with the constants folded: one fma into the rcp, x^2 and one multiply into
+// the exp2, four fmas (the 0.5 is in the coefficients), two multiplies.
+VA_DEVINL void gelu_parts(float x, float& half_erfc, float& gauss) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+    gauss = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));  // exp(-x^2/2)
+    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
+    half_erfc = (poly * t) * gauss;                                            // 0.5 * erfc(|x|/sqrt2)
 }
+// x * Phi(x) = max(x, 0) - |x| * half_erfc(|x|): no compare / select
 VA_DEVINL float gelu_erf(float x) {
-    float cdf, g;
-    gelu_parts(x, cdf, g);
-    return x * cdf;
+    float h, g;
+    gelu_parts(x, h, g);
+    return fmaf(-fabsf(x), h, fmaxf(x, 0.f));
 }
+// Phi(x) + x * phi(x)
 VA_DEVINL float gelu_erf_grad(float x) {
-    float cdf, g;
-    gelu_parts(x, cdf, g);
+    float h, g;
+    gelu_parts(x, h, g);
+    const float cdf = x >= 0.f ? 1.0f - h : h;
     return fmaf(x * 0.39894228040143268f, g, cdf);
 }
 
