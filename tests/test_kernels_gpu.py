@@ -55,6 +55,26 @@ def test_gemm_nt_plain(ops, dev, M, N, K, tile):
     assert (out.float() - ref).abs().max().item() < 0.06
 
 
+@pytest.mark.parametrize("tile", [256, 4256])
+def test_gemm_nt_strided_operands(ops, dev, tile):
+    """Row strides larger than the row length on every operand (views into wider buffers), ragged M."""
+    M, N, K = 2048 + 100, 512, 320
+    xs = rnd((M, 2 * K + 64), dev, 31, dtype=BF16)
+    ws = rnd((N, K + 8), dev, 32, 1.0 / math.sqrt(K), dtype=BF16)
+    x, w = xs[:, 64:64 + K], ws[:, :K]
+    ref = x.float() @ w.float().t()
+    wide = torch.full((M, N + 256), 7.0, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_BF16, wide[:, 128:128 + N], tile=tile)
+    assert rel_err(wide[:, 128:128 + N], ref) < 4e-3
+    assert (wide[:, :128] == 7).all() and (wide[:, 128 + N:] == 7).all()      # nothing outside the view is touched
+    wide32 = torch.full((M, N + 64), 7.0, dtype=F32, device=dev)
+    resid = rnd((M, N + 64), dev, 33)
+    bias = rnd((N,), dev, 34)
+    ops.gemm_nt(x, w, ops.EPI_F32, wide32[:, :N], bias=bias, resid=resid[:, :N], tile=tile)
+    assert (wide32[:, :N] - (ref + bias + resid[:, :N])).abs().max().item() < 2e-3
+    assert (wide32[:, N:] == 7).all()
+
+
 def test_gemm_nt_layout_is_not_transposed(ops, dev):
     """x = [I | 0] picks rows of w^T: catches a swapped row/column map that a random check could miss."""
     M, N, K = 128, 256, 128
