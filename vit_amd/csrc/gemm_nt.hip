@@ -27,6 +27,7 @@
 //         for small M and short K.
 #include "common.h"
 #include <type_traits>
+#include <atomic>
 
 namespace {
 
@@ -502,7 +503,8 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------------
 template <int EPI, bool HAS_BIAS, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                           int M, int N, int K, int ldx, int ldw, EpiArgs ep) {
+                                                           int M, int N, int K, int ldx, int ldw, EpiArgs ep,
+                                                           int* __restrict__ tk) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor type exists for the device target only; the host pass needs just the stub
     constexpr int BM = 256, BN = 256, BK = 32, NT = 256;
     constexpr int TM = 8, TN = 8;                 // per wave: 128 (m) x 128 (n)
@@ -614,16 +616,39 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     auto advance = [&](int sl) { return sl + 1 == RING ? 0 : sl + 1; };
     auto before = [&](int sl) { return sl == 0 ? RING - 1 : sl - 1; };
 
+    // Tiles after a workgroup's first are handed out at run time: a workgroup that starts late or runs slowly
+    // (its CU shared with another stream's kernel, a collective for one) simply takes fewer.  One counter per
+    // XCD class (block id mod 8) keeps a tile id congruent to its workgroup's class, which is what xcd_remap's
+    // locality rests on.  Thread 0 draws a ticket one tile ahead -- right before the epilogue, whose duration
+    // covers the atomic's round trip -- and passes it to the other waves through the one ring slot that is idle
+    // at a tile boundary (the slot of the tile's last stage; refilled only after the next stage-0 barrier).
+    const int xclass = blockIdx.x & 7;
+    const int vbase = (int)gridDim.x + ((xclass - (int)gridDim.x) & 7);    // first id of this class past the static round
+    auto draw = [&]() { return tid == 0 ? atomicAdd(tk + xclass, 1) : 0; };
+    auto lds_off = [&](int sl) { return (uint32_t)(uintptr_t)(lds_ptr_t)(smem + sl * STAGE_BYTES); };
+    auto post = [&](int sl, int ticket) {
+        if (tid == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds_off(sl)), "v"(ticket) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto collect = [&](int sl) {      // after the barrier that follows post()
+        int t;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(lds_off(sl)) : "memory");
+        return vbase + 8 * __builtin_amdgcn_readfirstlane(t);
+    };
+
     int v = blockIdx.x;
+    const int first_ticket = draw();
     Tile cur;
     set_tile(v, cur);
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
         for (int i = 0; i < LPS; ++i) load_one(cur, st, st, i);
+    post(RING - 1, first_ticket);
     wait_vm<3 * LPS>();                                   // stage 0 landed (own loads) ...
     __builtin_amdgcn_s_barrier();                          // ... and everybody else's
     asm volatile("" ::: "memory");
+    int vn = collect(RING - 1);                            // the tile after this one (>= tiles: none)
 #pragma unroll
     for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
 #pragma unroll
@@ -653,11 +678,11 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     using No = std::integral_constant<bool, false>;
     if (DBG == 5) t_last = __builtin_amdgcn_s_memtime();
     bool after_epilogue = false;
-    for (; v < tiles; v += gridDim.x) {
+    for (;;) {
         // the tile whose first four stages ride in this tile's last four bodies; after the last tile the same
         // loads are issued once more (valid addresses, never read) so that the counted waits stay uniform
         Tile nxt;
-        set_tile(v + (int)gridDim.x < tiles ? v + (int)gridDim.x : v, nxt);
+        set_tile(vn < tiles ? vn : v, nxt);
         // stage kt issues the loads of stage kt+4: of this tile, or of the next one from its stage 0 on
         auto stage_one = [&](auto parity, auto first, int kt, bool relaxed) {
             const bool in_cur = kt + 4 < nk;
@@ -676,16 +701,28 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 
         // the asm MFMAs are opaque to the compiler's hazard tracking: let the last results retire before they are read
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        const bool more = vn < tiles;
+        const int ticket = more ? draw() : 0;
         const bool full = cur.m0 + wm * 128 + 128 <= M;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             if (full) store_tile_wide<EPI, TM, true, HAS_BIAS, true>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
             else store_tile_wide<EPI, TM, false, HAS_BIAS>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
         }
+        if (!more) break;
+        post(before(slot), ticket);
+        __builtin_amdgcn_s_barrier();
+        v = vn;
+        vn = collect(before(slot));
         cur = nxt;
         after_epilogue = full;
     }
     wait_vm0();   // the trailing loads must not land in LDS after the workgroup has gone
+    // the last workgroup out rewinds the counters for the next launch that is given this set
+    if (tid == 0 && atomicAdd(tk + 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tk[i] = 0;
+    }
     if (DBG == 5 && lane == 0) {
         float* o = (float*)ep.out + ((size_t)blockIdx.x * 4 + wave) * 4;
         const uint64_t now = __builtin_amdgcn_s_memtime();
@@ -733,6 +770,27 @@ int launch_ring(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
     return VA_OK;
 }
 
+// Ticket counters of the persistent kernel: sets of 16 ints (8 per-XCD-class counters, one exit counter), all
+// zero between launches (the kernel rewinds its set on the way out).  Launches take sets round-robin so that
+// kernels running at the same time on different streams do not share one; QUAD_SETS launches in flight at
+// once on one device is the (unchecked) limit.
+constexpr int QUAD_SETS = 64;
+__device__ int quad_tickets[QUAD_SETS * 16];
+int* quad_ticket_set(int dev) {
+    static int* base[64] = {};
+    static std::atomic<unsigned> turn{0};
+    if (dev < 0 || dev >= 64) { va_set_error("va_gemm_nt: device index %d out of range", dev); return nullptr; }
+    if (!base[dev]) {
+        int* p = nullptr;
+        if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(quad_tickets)) != hipSuccess || !p) {
+            va_set_error("va_gemm_nt: cannot resolve the ticket counters");
+            return nullptr;
+        }
+        base[dev] = p;
+    }
+    return base[dev] + (turn.fetch_add(1, std::memory_order_relaxed) % QUAD_SETS) * 16;
+}
+
 template <int EPI, bool HAS_BIAS, int DBG = 0>
 int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
                 hipStream_t stream) {
@@ -749,7 +807,9 @@ int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
             cus[dev] = 256;
     }
     const int grid = tiles < cus[dev & 63] ? tiles : cus[dev & 63];
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, X, W, M, N, K, ldx, ldw, ep);
+    int* tk = quad_ticket_set(dev);
+    if (!tk) return VA_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, X, W, M, N, K, ldx, ldw, ep, tk);
     VA_CHECK_LAUNCH("va_gemm_nt");
     return VA_OK;
 }
