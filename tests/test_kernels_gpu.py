@@ -75,6 +75,33 @@ def test_gemm_nt_strided_operands(ops, dev, tile):
     assert (wide32[:, N:] == 7).all()
 
 
+def test_gemm_nt_persistent_tickets(ops, dev):
+    """The persistent kernel hands tiles out from counters that it rewinds itself: back-to-back launches and launches
+    running at the same time on two streams must each cover every tile exactly once (bit-identical results), for
+    tile counts below, at and above the number of CUs and not a multiple of 8."""
+    K = 256
+    w = rnd((768, K), dev, 41, 1.0 / math.sqrt(K), dtype=BF16)
+    cases = []
+    for M in (256 * 3 + 17, 256 * 86, 256 * 171 + 5):       # 12, 258 and 516 tiles
+        x = rnd((M, K), dev, 42 + M, dtype=BF16)
+        ref = torch.empty(M, 768, dtype=BF16, device=dev)
+        ops.gemm_nt(x, w, ops.EPI_BF16, ref, tile=256)       # one workgroup per tile, no counters
+        cases.append((x, ref))
+    side = torch.cuda.Stream()
+    outs = [[torch.zeros_like(ref) for _ in range(2)] for _, ref in cases]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for (x, ref), (o_main, o_side) in zip(cases, outs):
+            o_main.zero_(); o_side.zero_()
+            side.wait_stream(torch.cuda.current_stream())
+            ops.gemm_nt(x, w, ops.EPI_BF16, o_main, tile=4256)
+            with torch.cuda.stream(side):
+                ops.gemm_nt(x, w, ops.EPI_BF16, o_side, tile=4256)
+            ops.gemm_nt(x, w, ops.EPI_BF16, o_main, tile=4256)          # again, right behind the first
+            torch.cuda.current_stream().wait_stream(side)
+            assert torch.equal(o_main, ref) and torch.equal(o_side, ref)
+
+
 def test_gemm_nt_layout_is_not_transposed(ops, dev):
     """x = [I | 0] picks rows of w^T: catches a swapped row/column map that a random check could miss."""
     M, N, K = 128, 256, 128

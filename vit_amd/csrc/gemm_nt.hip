@@ -27,7 +27,7 @@
 //         for small M and short K.
 #include "common.h"
 #include <type_traits>
-#include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -497,7 +497,8 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
 // burst and the matrix pipe is never left waiting behind a queue of load issues.
 // Same LDS image as the ring (BK = 32 stages, 5 slots, chunk XOR, permuted weight rows); one barrier per stage:
 // at the top of stage kt the loads of kt+2 and kt+3 may still be in flight.
-// The kernel is persistent: one workgroup per CU walks tiles v, v + grid, ...  The LDS ring never drains between
+// The kernel is persistent: one workgroup per CU takes tile `block id` and then draws further tiles from shared
+// counters until none is left.  The LDS ring never drains between
 // tiles -- the last four stages of a tile issue the first four stages of the next one, so the only bubble at a
 // tile boundary is the epilogue itself, not a load round trip.
 // ------------------------------------------------------------------------------------------------
@@ -771,24 +772,38 @@ int launch_ring(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
 }
 
 // Ticket counters of the persistent kernel: sets of 16 ints (8 per-XCD-class counters, one exit counter), all
-// zero between launches (the kernel rewinds its set on the way out).  Launches take sets round-robin so that
-// kernels running at the same time on different streams do not share one; QUAD_SETS launches in flight at
-// once on one device is the (unchecked) limit.
+// zero between launches (the kernel rewinds its set on the way out).  A set belongs to a (device, stream) pair:
+// launches on one stream run in order and may share a set, launches on different streams may run at the same
+// time and must not.  A device serves QUAD_SETS distinct streams this way; a launch on a further stream gets
+// no set (*none = true) and the caller uses the non-persistent kernel instead.  (A captured graph holds the set
+// of the stream it was captured on: replaying it on several streams at once is not supported.)
 constexpr int QUAD_SETS = 64;
 __device__ int quad_tickets[QUAD_SETS * 16];
-int* quad_ticket_set(int dev) {
-    static int* base[64] = {};
-    static std::atomic<unsigned> turn{0};
+int* quad_ticket_set(int dev, hipStream_t stream, bool* none) {
+    struct PerDevice {
+        int* base = nullptr;
+        int used = 0;
+        hipStream_t owner[QUAD_SETS];
+    };
+    static PerDevice table[64];
+    static std::mutex lock;
+    *none = false;
     if (dev < 0 || dev >= 64) { va_set_error("va_gemm_nt: device index %d out of range", dev); return nullptr; }
-    if (!base[dev]) {
+    std::lock_guard<std::mutex> guard(lock);
+    PerDevice& t = table[dev];
+    if (!t.base) {
         int* p = nullptr;
         if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(quad_tickets)) != hipSuccess || !p) {
             va_set_error("va_gemm_nt: cannot resolve the ticket counters");
             return nullptr;
         }
-        base[dev] = p;
+        t.base = p;
     }
-    return base[dev] + (turn.fetch_add(1, std::memory_order_relaxed) % QUAD_SETS) * 16;
+    for (int i = 0; i < t.used; ++i)
+        if (t.owner[i] == stream) return t.base + i * 16;
+    if (t.used == QUAD_SETS) { *none = true; return nullptr; }
+    t.owner[t.used] = stream;
+    return t.base + (t.used++) * 16;
 }
 
 template <int EPI, bool HAS_BIAS, int DBG = 0>
@@ -807,7 +822,9 @@ int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
             cus[dev] = 256;
     }
     const int grid = tiles < cus[dev & 63] ? tiles : cus[dev & 63];
-    int* tk = quad_ticket_set(dev);
+    bool none = false;
+    int* tk = quad_ticket_set(dev, stream, &none);
+    if (none) return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
     if (!tk) return VA_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, X, W, M, N, K, ldx, ldw, ep, tk);
     VA_CHECK_LAUNCH("va_gemm_nt");
