@@ -66,6 +66,13 @@ int va_colsum_bf16_accum(const void* y, int64_t M, int64_t N, int64_t ldy, float
 int va_tubelet_gather(const float* video, void* patches, int64_t B, int64_t C, int64_t T, int64_t H, int64_t W,
                       int64_t tt, int64_t th, int64_t tw, va_stream_t stream);
 
+/* The adjoint placement: patches [tokens, C*tt*th*tw] f32 (gradient of the patch matrix) -> video gradient
+ * (B,C,T,H,W) f32; pixels outside every tubelet (T, H or W not a multiple of the tubelet) are left untouched,
+ * so the caller zero-fills those.  The input-gradient half of the Conv3d backward (autograd of swm:78-84, 99).
+ * tw % 4 == 0. */
+int va_tubelet_scatter(const float* patches, float* video, int64_t B, int64_t C, int64_t T, int64_t H, int64_t W,
+                       int64_t tt, int64_t th, int64_t tw, va_stream_t stream);
+
 /* ---- LayerNorm (nn.LayerNorm, eps 1e-6; swm:686, 695, 757) ---------------------------------------
  * forward: x f32 [M,D] -> y (bf16 if out_bf16 else f32) [M,D]; also stores mean/rstd [M] for backward. */
 int va_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, float* mean,

@@ -42,7 +42,7 @@ def test_encoder_matches_reference_golden(swm, golden_dir, tag):
     g = np.load(os.path.join(golden_dir, f"encoder_{tag}.npz"), allow_pickle=False)
     depth, heads, B, frames, img = (int(v) for v in g["cfg"])
     enc = build(swm, depth, heads, frames, img)
-    video = torch.from_numpy(g["video"]).cuda()
+    video = torch.from_numpy(g["video"]).cuda().requires_grad_(True)
     y = enc(video)
     ref_y = torch.from_numpy(g["y"])
     assert y.shape == ref_y.shape and y.dtype == torch.float32
@@ -57,7 +57,34 @@ def test_encoder_matches_reference_golden(swm, golden_dir, tag):
         worst = max(worst, e)
         assert e < 5e-2, (k, e)            # 64 sampled entries: looser than the full-tensor bound below
         np.testing.assert_allclose(flat.abs().sum().item(), g[f"g:{k}:digest"][1], rtol=2e-2, err_msg=k)
-    print(f"[{tag}] y rel {rel(y, ref_y):.2e}, worst sampled-grad rel {worst:.2e}")
+    # gradient of the clip itself (the reference gets it from autograd through the Conv3d)
+    assert video.grad is not None and video.grad.shape == video.shape
+    e_in = rel(video.grad, torch.from_numpy(g["dvideo"]))
+    assert e_in < REL_TOL, e_in
+    print(f"[{tag}] y rel {rel(y, ref_y):.2e}, worst sampled-grad rel {worst:.2e}, input-grad rel {e_in:.2e}")
+
+
+def test_input_gradient_only_and_ragged_clip(swm):
+    """Frozen encoder with a clip that requires grad (no parameter gradient is produced), on a clip whose frame
+    count and size are not multiples of the tubelet: uncovered pixels get a zero gradient, the rest matches the
+    oracle's autograd."""
+    enc = build(swm, 1, 16, 5, 72)
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    video = R.hashed_uniform("test.video.ragged", (2, 3, 5, 72, 72), 1.0)
+    P = R.make_encoder_params(1, requires_grad=False)
+    v_ref = video.clone().requires_grad_(True)
+    ref = R.encoder_forward(P, v_ref, 1, 16)
+    gy = R.hashed_uniform("test.gy.ragged", tuple(ref.shape), 1.0)
+    (ref * gy).sum().backward()
+    v = video.cuda().requires_grad_(True)
+    y = enc(v)
+    (y * gy.cuda()).sum().backward()
+    assert all(p.grad is None for p in enc.parameters())
+    assert rel(v.grad, v_ref.grad) < REL_TOL
+    got = v.grad.cpu()
+    assert (got[:, :, 4:] == 0).all() and (got[:, :, :, 64:] == 0).all() and (got[:, :, :, :, 64:] == 0).all()
+    assert (v_ref.grad[:, :, 4:] == 0).all()
 
 
 @pytest.mark.parametrize("depth,heads,B,frames,img", [(2, 16, 2, 8, 64), (1, 8, 3, 4, 80), (1, 16, 2, 16, 224)])

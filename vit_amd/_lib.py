@@ -29,6 +29,7 @@ SIGNATURES = {
     "va_gemm_tn_accum": (ci, [vp, vp, i64, i64, i64, i64, i64, vp, i64, vp, ci, vp]),
     "va_colsum_bf16_accum": (ci, [vp, i64, i64, i64, vp, vp]),
     "va_tubelet_gather": (ci, [vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp]),
+    "va_tubelet_scatter": (ci, [vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp]),
     "va_layernorm_fwd": (ci, [vp, vp, vp, vp, ci, vp, vp, i64, i64, cf, vp]),
     "va_layernorm_bwd_partial_rows": (i64, [i64]),
     "va_layernorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),

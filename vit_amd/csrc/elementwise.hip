@@ -236,6 +236,26 @@ __global__ __launch_bounds__(256) void tubelet_gather_kernel(const float* __rest
     *(u32x4_t*)(patches + token * kdim + col) = pack8(f);
 }
 
+// The inverse placement for the input gradient: patch-matrix rows (f32) back to (B,C,T,H,W); one thread per 4
+// consecutive pixels of a patch row.  Tubelets do not overlap, so every covered pixel is written exactly once.
+__global__ __launch_bounds__(256) void tubelet_scatter_kernel(const float* __restrict__ patches, float* __restrict__ video,
+                                                              int64_t total_chunks, int C, int T, int H, int W, int tt,
+                                                              int th, int tw) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_chunks) return;
+    const int Tp = T / tt, Hp = H / th, Wp = W / tw;
+    const int kdim = C * tt * th * tw, cpr = kdim / 4;
+    const int64_t token = gid / cpr;
+    const int col = (int)(gid % cpr) * 4;
+    const int dw = col % tw, dh = (col / tw) % th, dt = (col / (tw * th)) % tt, c = col / (tw * th * tt);
+    const int ntok = Tp * Hp * Wp;
+    const int64_t b = token / ntok;
+    const int n = (int)(token % ntok);
+    const int tp = n / (Hp * Wp), hp = (n / Wp) % Hp, wp = n % Wp;
+    float* dst = video + ((((b * C + c) * T + (tp * tt + dt)) * H + (hp * th + dh)) * (int64_t)W + wp * tw + dw);
+    *(f32x4_t*)dst = *(const f32x4_t*)(patches + token * kdim + col);
+}
+
 // ------------------------------------------------------------------------------------------------
 // casts
 // ------------------------------------------------------------------------------------------------
@@ -537,6 +557,20 @@ extern "C" int va_tubelet_gather(const float* video, void* patches, int64_t B, i
     hipLaunchKernelGGL(tubelet_gather_kernel, dim3(blocks_for(chunks, 256)), dim3(256), 0, stream, video,
                        (bf16_t*)patches, chunks, (int)C, (int)T, (int)H, (int)W, (int)tt, (int)th, (int)tw);
     VA_CHECK_LAUNCH("va_tubelet_gather");
+    return VA_OK;
+}
+
+extern "C" int va_tubelet_scatter(const float* patches, float* video, int64_t B, int64_t C, int64_t T, int64_t H,
+                                  int64_t W, int64_t tt, int64_t th, int64_t tw, hipStream_t stream) {
+    VA_CHECK_ARG(video && patches, "va_tubelet_scatter: null operand");
+    VA_CHECK_ARG(B > 0 && C > 0 && tt > 0 && th > 0 && tw > 0 && T >= tt && H >= th && W >= tw, "va_tubelet_scatter: bad shape");
+    VA_CHECK_ARG(tw % 4 == 0 && W % 4 == 0, "va_tubelet_scatter: tubelet width and W must be multiples of 4");
+    VA_CHECK_ARG(((uintptr_t)video | (uintptr_t)patches) % 16 == 0, "va_tubelet_scatter: misaligned operand");
+    const int64_t tokens = B * (T / tt) * (H / th) * (W / tw);
+    const int64_t chunks = tokens * (C * tt * th * tw / 4);
+    hipLaunchKernelGGL(tubelet_scatter_kernel, dim3(blocks_for(chunks, 256)), dim3(256), 0, stream, patches, video,
+                       chunks, (int)C, (int)T, (int)H, (int)W, (int)tt, (int)th, (int)tw);
+    VA_CHECK_LAUNCH("va_tubelet_scatter");
     return VA_OK;
 }
 

@@ -130,6 +130,7 @@ class EncoderContext:
     mean_f: Optional[torch.Tensor] = None
     rstd_f: Optional[torch.Tensor] = None
     drop: Optional["DropPlan"] = None
+    video_shape: Optional[Tuple[int, ...]] = None
 
 
 @dataclass
@@ -198,7 +199,7 @@ class EncoderEngine:
         x = new(D, F32)
         ops.gemm_nt(patches, Wc.fwd("pe", P["tubelet_embed.projection.weight"]), ops.EPI_F32, x,
                     bias=P["tubelet_embed.projection.bias"])
-        ctx = EncoderContext(cfg, B, N, grid, tables, patches, drop=drop) if save else None
+        ctx = EncoderContext(cfg, B, N, grid, tables, patches, drop=drop, video_shape=tuple(video.shape)) if save else None
         if drop is not None and (len(drop.p) != cfg.depth or len(drop.keys) != cfg.depth):
             raise ValueError("dropout plan does not match the encoder depth")
 
@@ -266,8 +267,10 @@ class EncoderEngine:
 
     # ---------------------------------------------------------------- backward
     def backward(self, P: Dict[str, torch.Tensor], ctx: EncoderContext, grad_out: torch.Tensor,
-                 on_block_done: Optional[Callable[[torch.Tensor], None]] = None) -> Dict[str, torch.Tensor]:
-        """grad_out: (B,N,D).  Returns name -> f32 gradient (views into one flat buffer per block).
+                 on_block_done: Optional[Callable[[torch.Tensor], None]] = None,
+                 input_grad: bool = False) -> Dict[str, torch.Tensor]:
+        """grad_out: (B,N,D).  Returns name -> f32 gradient (views into one flat buffer per block); with
+        `input_grad` also "video" -> gradient of the clip (B,C,T,H,W), the input half of the Conv3d backward.
         `on_block_done(flat)` is called right after a block's (and finally the stem's) gradient launches
         have been enqueued; the data-parallel reducer hooks in there."""
         cfg = self.cfg
@@ -340,4 +343,8 @@ class EncoderEngine:
                           dbias=grads["tubelet_embed.projection.bias"])
         if on_block_done is not None:
             on_block_done(stem)
+        if input_grad:
+            d_patches = torch.empty(M, ctx.patches.shape[1], dtype=F32, device=dev)
+            ops.gemm_nt(g_bf, Wc.bwd("pe", pw), ops.EPI_F32, d_patches)
+            grads["video"] = ops.tubelet_scatter(d_patches, ctx.video_shape, cfg.tubelet)
         return grads

@@ -110,6 +110,21 @@ def tubelet_gather(video: torch.Tensor, tubelet: Tuple[int, int, int], patches: 
     return patches
 
 
+def tubelet_scatter(patches: torch.Tensor, video_shape, tubelet: Tuple[int, int, int]) -> torch.Tensor:
+    """Gradient of the patch matrix (f32 [tokens, C*tt*th*tw]) -> gradient of the video (B,C,T,H,W) f32."""
+    _need(patches, F32, "patches")
+    B, C, T, H, W = (int(v) for v in video_shape)
+    tt, th, tw = tubelet
+    M = B * (T // tt) * (H // th) * (W // tw)
+    Kd = C * tt * th * tw
+    if tuple(patches.shape) != (M, Kd) or not patches.is_contiguous():
+        raise ValueError("tubelet_scatter: bad patches buffer")
+    exact = T % tt == 0 and H % th == 0 and W % tw == 0
+    video = (torch.empty if exact else torch.zeros)(B, C, T, H, W, dtype=F32, device=patches.device)
+    check(_lib.load().va_tubelet_scatter(_p(patches), _p(video), B, C, T, H, W, tt, th, tw, _stream()), "va_tubelet_scatter")
+    return video
+
+
 # ------------------------------------------------------------------ LayerNorm
 def layernorm_fwd(x, gamma, beta, out, mean, rstd, eps: float = 1e-6):
     _need(x, F32, "x"); _need(gamma, F32, "gamma"); _need(beta, F32, "beta")

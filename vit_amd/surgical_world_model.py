@@ -145,10 +145,8 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module: "VideoViTEncoder", video: torch.Tensor, *params: torch.Tensor):
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("gradient with respect to the input video is not implemented")
         P = module._tensor_table(params)
-        save = any(ctx.needs_input_grad[2:])
+        save = any(ctx.needs_input_grad[1:])
         out, ectx = module._engine.forward(P, video, save=save, drop=module._dropout_plan())
         ctx.module, ctx.ectx, ctx.P = module, ectx, P
         return out
@@ -158,12 +156,14 @@ class _EncoderFn(torch.autograd.Function):
         module = ctx.module
         reducer = module._grad_reducer
         grads = module._engine.backward(ctx.P, ctx.ectx, grad_out,
-                                        on_block_done=reducer.submit if reducer is not None else None)
+                                        on_block_done=reducer.submit if reducer is not None else None,
+                                        input_grad=ctx.needs_input_grad[1])
         if reducer is not None:
             reducer.finish()
         ctx.ectx = None
         names = module._param_order
-        return (None, None) + tuple(grads[n] if need else None for n, need in zip(names, ctx.needs_input_grad[2:]))
+        return (None, grads.get("video")) + tuple(grads[n] if need else None
+                                                  for n, need in zip(names, ctx.needs_input_grad[2:]))
 
 
 class VideoViTEncoder(nn.Module):
