@@ -44,16 +44,16 @@ class GemmProbe:
         self._orig = ops.gemm_nt
 
     def install(self):
-        def wrapped(x, w, epilogue, out, out2=None, bias=None, resid=None, aux=None, tile=0):
+        def wrapped(x, w, epilogue, out, out2=None, bias=None, resid=None, aux=None, tile=0, **kw):
             M, K = x.shape
             N = w.shape[0]
             dominant = self.enabled and epilogue == self.ops.EPI_BF16 and bias is None and N % 256 == 0 and M >= 2048 \
                 and tile in (0, 256, 4256)
             if not dominant:
-                return self._orig(x, w, epilogue, out, out2, bias, resid, aux, tile)
+                return self._orig(x, w, epilogue, out, out2, bias, resid, aux, tile, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = self._orig(x, w, epilogue, out, out2, bias, resid, aux, tile)
+            r = self._orig(x, w, epilogue, out, out2, bias, resid, aux, tile, **kw)
             e.record()
             self.records.append((2.0 * M * N * K, s, e))
             return r

@@ -47,6 +47,14 @@ int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, int64_t K, in
                int epilogue, void* out, void* out2, const float* bias, const float* resid, const void* aux,
                int64_t ldc, int tile, va_stream_t stream);
 
+/* The same with a training-mode dropout (nn.Dropout of swm:700, 702 and its backward) folded into the epilogue,
+ * with the decisions va_dropout(key, p) makes over the contiguous [M,N] output (ldc == N, M*N < 2^32):
+ *   VA_EPI_BIAS_GELU: out2 = drop(gelu(acc + bias));  VA_EPI_F32: out = drop(acc + bias) + resid;
+ *   VA_EPI_GELU_BWD:  out = drop(acc * gelu'(aux)).   p == 0 is va_gemm_nt.  Not with tile >= 4256. */
+int va_gemm_nt_dropout(const void* x, const void* w, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                       int epilogue, void* out, void* out2, const float* bias, const float* resid, const void* aux,
+                       int64_t ldc, int tile, uint32_t key, float p, va_stream_t stream);
+
 /* dw[N,K] (f32) += dy[M,N]^T * x[M,K]: the weight-gradient half of nn.Linear's backward (autograd of
  * swm:296, 334, 698-701, 102).  bf16 operands, split over M in `split_k` slices (0 = choose; negative =
  * |split_k| slices on the small-tile kernel) that are
@@ -84,6 +92,12 @@ int64_t va_layernorm_bwd_partial_rows(int64_t M);
 int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
                      const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16, float* partial,
                      float* dgamma, float* dbeta, int64_t M, int64_t D, va_stream_t stream);
+/* The same, with dx_bf16 = va_dropout(dx_out; key, p) instead of a plain copy: the bf16 copy is the operand of the
+ * gradient GEMMs of a branch that sits behind an nn.Dropout (swm:702); dx_out itself stays undropped. */
+int va_layernorm_bwd_dropout(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                             const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16, float* partial,
+                             float* dgamma, float* dbeta, int64_t M, int64_t D, uint32_t key, float p,
+                             va_stream_t stream);
 
 /* ---- 3D rotary embedding (swm:33-51, 265-281) ------------------------------------------------------
  * In-place rotation of the Q and K thirds of a packed qkv buffer [M, 3*D] bf16 (D = 1024, column

@@ -83,6 +83,72 @@ def test_dropout_rejects_bad_arguments(ops, dev):
         ops.dropout(rnd((3, 5), dev, 1), 1, 0.1)      # 15 elements: not a multiple of 8
 
 
+# ------------------------------------------------------------------------------ dropout inside the GEMM epilogues
+@pytest.mark.parametrize("M,tile", [(700, 128), (2048 + 40, 256), (256 * 9, 0)])
+def test_gemm_epilogue_dropout(ops, dev, M, tile):
+    """The three fused sites against GEMM-then-va_dropout: identical masks (the documented hash over the contiguous
+    output), f32 site bit-identical, bf16 sites equal up to the one rounding the fusion saves."""
+    N, K, p, key = 1024, 512, 0.1, 0x1234ABCD
+    x = rnd((M, K), dev, 11, dtype=BF16)
+    w = rnd((N, K), dev, 12, 1.0 / math.sqrt(K), dtype=BF16)
+    bias = rnd((N,), dev, 13, 0.5)
+    resid = rnd((M, N), dev, 14)
+    mask = R.drop_mask(key, (M, N), p).to(dev)            # 0 or 1 / (1 - p)
+    # f32 + bias, dropout, + residual
+    plain = torch.empty(M, N, dtype=F32, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_F32, plain, bias=bias, tile=tile)
+    want = ops.dropout(plain, key, p, out=torch.empty_like(plain), resid=resid)
+    got = torch.empty_like(plain)
+    ops.gemm_nt(x, w, ops.EPI_F32, got, bias=bias, resid=resid, tile=tile, drop_key=key, drop_p=p)
+    assert torch.equal(got, want)
+    # bias + GELU: first output untouched, second one dropped
+    pre0, act0 = torch.empty(M, N, dtype=BF16, device=dev), torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_BIAS_GELU, pre0, out2=act0, bias=bias, tile=tile)
+    pre1, act1 = torch.empty_like(pre0), torch.empty_like(act0)
+    ops.gemm_nt(x, w, ops.EPI_BIAS_GELU, pre1, out2=act1, bias=bias, tile=tile, drop_key=key, drop_p=p)
+    assert torch.equal(pre1, pre0)
+    assert torch.equal(act1 == 0, (mask == 0) | (act0 == 0))
+    ref_act = R.gelu_erf((x.float() @ w.float().t() + bias).cpu()).to(dev) * mask
+    assert rel_err(act1, ref_act) < 4e-3
+    assert (act1.float() - act0.float() * mask).abs().max().item() <= 2 ** -7 * (act0.float().abs() * mask).max().item()
+    # GELU backward
+    d0, d1 = torch.empty(M, N, dtype=BF16, device=dev), torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_GELU_BWD, d0, aux=pre0, tile=tile)
+    ops.gemm_nt(x, w, ops.EPI_GELU_BWD, d1, aux=pre0, tile=tile, drop_key=key, drop_p=p)
+    assert torch.equal(d1 == 0, (mask == 0) | (d0 == 0))
+    assert (d1.float() - d0.float() * mask).abs().max().item() <= 2 ** -7 * (d0.float().abs() * mask).max().item()
+    # refusals: no dropout site in the plain epilogue, strided output, the four-wave kernel
+    with pytest.raises(Exception):
+        ops.gemm_nt(x, w, ops.EPI_BF16, d0, drop_key=key, drop_p=p)
+    wide = torch.empty(M, 2 * N, dtype=F32, device=dev)
+    with pytest.raises(Exception):
+        ops.gemm_nt(x, w, ops.EPI_F32, wide[:, :N], drop_key=key, drop_p=p)
+    if M >= 2048:
+        with pytest.raises(Exception):
+            ops.gemm_nt(x, w, ops.EPI_F32, got, tile=4256, drop_key=key, drop_p=p)
+
+
+def test_layernorm_bwd_dropped_copy(ops, dev):
+    """The bf16 copy of LayerNorm backward with a mask folded in: the f32 output and the parameter gradients are
+    those of the plain call, the copy is dropout(f32 output) rounded once."""
+    M, D, p, key = 517, 1024, 0.1, 0xBEEF
+    x, dy, resid = rnd((M, D), dev, 21), rnd((M, D), dev, 22, dtype=BF16), rnd((M, D), dev, 23)
+    gamma = rnd((D,), dev, 24) + 1.0
+    mean = x.mean(1)
+    rstd = torch.rsqrt(x.var(1, unbiased=False) + 1e-6)
+    outs = []
+    for kw in ({}, {"drop_key": key, "drop_p": p}):
+        dx, dxb = torch.empty(M, D, dtype=F32, device=dev), torch.empty(M, D, dtype=BF16, device=dev)
+        dg, db = torch.empty(D, dtype=F32, device=dev), torch.empty(D, dtype=F32, device=dev)
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, resid, dx, dxb, dg, db, **kw)
+        outs.append((dx, dxb, dg, db))
+    (dx0, dxb0, dg0, db0), (dx1, dxb1, dg1, db1) = outs
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(dxb0, dx0.to(BF16))
+    mask = R.drop_mask(key, (M, D), p).to(dev)
+    assert torch.equal(dxb1, (dx0 * mask).to(BF16))
+
+
 # ------------------------------------------------------------------------------ attention
 def attn_reference(qkv, B, N, H, mask):
     D = qkv.shape[1] // 3

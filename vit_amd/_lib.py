@@ -26,6 +26,7 @@ SIGNATURES = {
     "va_version": (ci, []),
     "va_last_error": (c_char_p, []),
     "va_gemm_nt": (ci, [vp, vp, i64, i64, i64, i64, i64, ci, vp, vp, vp, vp, vp, i64, ci, vp]),
+    "va_gemm_nt_dropout": (ci, [vp, vp, i64, i64, i64, i64, i64, ci, vp, vp, vp, vp, vp, i64, ci, cu32, cf, vp]),
     "va_gemm_tn_accum": (ci, [vp, vp, i64, i64, i64, i64, i64, vp, i64, vp, ci, vp]),
     "va_colsum_bf16_accum": (ci, [vp, i64, i64, i64, vp, vp]),
     "va_tubelet_gather": (ci, [vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp]),
@@ -33,6 +34,7 @@ SIGNATURES = {
     "va_layernorm_fwd": (ci, [vp, vp, vp, vp, ci, vp, vp, i64, i64, cf, vp]),
     "va_layernorm_bwd_partial_rows": (i64, [i64]),
     "va_layernorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
+    "va_layernorm_bwd_dropout": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, cu32, cf, vp]),
     "va_rope3d_qk_inplace": (ci, [vp, vp, i64, i64, i64, i64, ci, vp]),
     "va_attn_fwd": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp]),
     "va_attn_fwd_block_causal": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),

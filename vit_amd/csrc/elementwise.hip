@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ resid_grad, float* __restrict__ dx_out,
                                                      bf16_t* __restrict__ dx_bf16, float* __restrict__ partial,
-                                                     int64_t M) {
+                                                     int64_t M, uint32_t drop_key, uint32_t drop_thi, float drop_scale) {
     __shared__ float red[2][4][LN_D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4_t gm[4];
@@ -136,8 +136,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 for (int j = 0; j < 4; ++j) o[j] += r[j];
             }
             *(f32x4_t*)(dx_out + row * LN_D + c) = (f32x4_t){o[0], o[1], o[2], o[3]};
-            if (dx_bf16 != nullptr)
+            if (dx_bf16 != nullptr) {
+                if (drop_thi) {   // the bf16 copy feeds a branch behind a dropout: it carries that dropout's mask
+                    const uint32_t w0 = drop_weyl(drop_key, (uint32_t)((row * LN_D + c) >> 1));
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t hsh = drop_mix(w0 + (uint32_t)q * DROP_WEYL);
+                        o[2 * q] = drop_keep_even(hsh, drop_thi) ? __fmul_rn(o[2 * q], drop_scale) : 0.f;
+                        o[2 * q + 1] = drop_keep_odd(hsh, drop_thi) ? __fmul_rn(o[2 * q + 1], drop_scale) : 0.f;
+                    }
+                }
                 *(u32x2_t*)(dx_bf16 + row * LN_D + c) = (u32x2_t){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            }
         }
     }
 #pragma unroll
@@ -513,9 +523,16 @@ extern "C" int64_t va_layernorm_bwd_partial_rows(int64_t M) {
     return need < LN_BWD_BLOCKS ? need : LN_BWD_BLOCKS;
 }
 
-extern "C" int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
-                                const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16,
-                                float* partial, float* dgamma, float* dbeta, int64_t M, int64_t D, hipStream_t stream) {
+extern "C" int va_layernorm_bwd_dropout(const void* dy, int dy_bf16, const float* x, const float* gamma,
+                                        const float* mean, const float* rstd, const float* resid_grad, float* dx_out,
+                                        void* dx_bf16, float* partial, float* dgamma, float* dbeta, int64_t M,
+                                        int64_t D, uint32_t key, float p, hipStream_t stream) {
+    VA_CHECK_ARG(p >= 0.f && p < 1.f, "va_layernorm_bwd: dropout probability %g outside [0, 1)", (double)p);
+    const uint32_t thresh = va_drop_thresh16(p);
+    VA_CHECK_ARG(thresh < 65536u, "va_layernorm_bwd: dropout probability %g rounds to 1", (double)p);
+    VA_CHECK_ARG(thresh == 0 || (dx_bf16 && M * D < (1ll << 32)), "va_layernorm_bwd: dropout needs the bf16 output and fewer than 2^32 elements");
+    const uint32_t thi = thresh << 16;
+    const float dscale = va_drop_scale(thresh);
     VA_CHECK_ARG(dy && x && gamma && mean && rstd && dx_out && partial && dgamma && dbeta, "va_layernorm_bwd: null operand");
     VA_CHECK_ARG(D == LN_D, "va_layernorm_bwd: width %lld not supported (the encoder is 1024 wide)", (long long)D);
     VA_CHECK_ARG(M > 0, "va_layernorm_bwd: empty input");
@@ -523,14 +540,21 @@ extern "C" int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, con
     const int nblk = (int)va_layernorm_bwd_partial_rows(M);
     if (dy_bf16)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, dy, x, gamma, mean, rstd, resid_grad,
-                           dx_out, (bf16_t*)dx_bf16, partial, M);
+                           dx_out, (bf16_t*)dx_bf16, partial, M, key, thi, dscale);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, dy, x, gamma, mean, rstd, resid_grad,
-                           dx_out, (bf16_t*)dx_bf16, partial, M);
+                           dx_out, (bf16_t*)dx_bf16, partial, M, key, thi, dscale);
     VA_CHECK_LAUNCH("va_layernorm_bwd");
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * LN_D / 16), dim3(256), 0, stream, partial, nblk, dgamma, dbeta);
     VA_CHECK_LAUNCH("va_layernorm_bwd(reduce)");
     return VA_OK;
+}
+
+extern "C" int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16,
+                                float* partial, float* dgamma, float* dbeta, int64_t M, int64_t D, hipStream_t stream) {
+    return va_layernorm_bwd_dropout(dy, dy_bf16, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, partial, dgamma, dbeta,
+                                    M, D, 0u, 0.f, stream);
 }
 
 extern "C" int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, int64_t Tp, int64_t Hp, int64_t Wp,

@@ -38,7 +38,24 @@ struct EpiArgs {
     const float* resid;   // f32 [M, ldc] or null (VA_EPI_F32)
     const bf16_t* aux;    // bf16 [M, ldc]: saved pre-activation (VA_EPI_GELU_BWD)
     int ldc;
+    // Fused dropout (drop_thi != 0): applied to the GELU output (BIAS_GELU: out2), to acc + bias before the residual
+    // (F32), to the product with the GELU derivative (GELU_BWD).  Decisions are those of va_dropout over a contiguous
+    // [M, N] matrix: element index m * N + n, so the output must be stored with ldc == N.
+    uint32_t drop_key, drop_thi;
+    float drop_scale;
 };
+
+// keep-or-zero and rescale of `cnt` (even) consecutive elements starting at element index e0 (even)
+template <int CNT>
+VA_DEVINL void drop_run(float* v, uint32_t e0, const EpiArgs& ep) {
+    const uint32_t w0 = drop_weyl(ep.drop_key, e0 >> 1);
+#pragma unroll
+    for (int q = 0; q < CNT / 2; ++q) {
+        const uint32_t hsh = drop_mix(w0 + (uint32_t)q * DROP_WEYL);
+        v[2 * q] = drop_keep_even(hsh, ep.drop_thi) ? __fmul_rn(v[2 * q], ep.drop_scale) : 0.f;
+        v[2 * q + 1] = drop_keep_odd(hsh, ep.drop_thi) ? __fmul_rn(v[2 * q + 1], ep.drop_scale) : 0.f;
+    }
+}
 
 // Epilogue for a wave's accumulators acc[a][b] (a: 16-column block of n, b: 16-row block of m).
 // Lane holds D rows n = nb..nb+3 (4 consecutive output columns) for output row m.
@@ -65,9 +82,12 @@ VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M
             } else if (EPI == VA_EPI_BIAS_GELU) {
                 u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *(u32x2_t*)((bf16_t*)ep.out + o) = pk;
-                u32x2_t gk = {pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]))};
+                float gl[4] = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+                if (ep.drop_thi) drop_run<4>(gl, (uint32_t)o, ep);
+                u32x2_t gk = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3])};
                 *(u32x2_t*)((bf16_t*)ep.out2 + o) = gk;
             } else if (EPI == VA_EPI_F32) {
+                if (ep.drop_thi) drop_run<4>(v, (uint32_t)o, ep);
                 if (ep.resid != nullptr) {
                     const f32x4_t rv = *(const f32x4_t*)(ep.resid + o);
 #pragma unroll
@@ -78,8 +98,10 @@ VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M
                 const u32x2_t pre = *(const u32x2_t*)(ep.aux + o);
                 const float p0 = __uint_as_float(pre[0] << 16), p1 = __uint_as_float(pre[0] & 0xffff0000u);
                 const float p2 = __uint_as_float(pre[1] << 16), p3 = __uint_as_float(pre[1] & 0xffff0000u);
-                u32x2_t pk = {pack_bf16x2(v[0] * gelu_erf_grad(p0), v[1] * gelu_erf_grad(p1)),
-                              pack_bf16x2(v[2] * gelu_erf_grad(p2), v[3] * gelu_erf_grad(p3))};
+                float r[4] = {v[0] * gelu_erf_grad(p0), v[1] * gelu_erf_grad(p1), v[2] * gelu_erf_grad(p2),
+                              v[3] * gelu_erf_grad(p3)};
+                if (ep.drop_thi) drop_run<4>(r, (uint32_t)o, ep);
+                u32x2_t pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
                 *(u32x2_t*)((bf16_t*)ep.out + o) = pk;
             }
         }
@@ -109,7 +131,8 @@ VA_DEVINL int wide_wrow(int row) {
 // block is processed, instead of four loads in front of each row block's stores (the compiler may not move loads
 // of `resid` above stores to `out` on its own).  Safe for out == resid: a lane reads exactly the elements it later
 // writes.  Costs 4*TM*4 registers: for the kernel whose accumulators live in the accumulation registers.
-template <int EPI, int TM, bool FULL_M = false, bool HAS_BIAS = true, bool RESID_AHEAD = false>
+// CAN_DROP = false compiles the fused-dropout branches out (the four-wave kernel has no registers to spare for them).
+template <int EPI, int TM, bool FULL_M = false, bool HAS_BIAS = true, bool RESID_AHEAD = false, bool CAN_DROP = true>
 VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
     const int ldc = ep.ldc;
     const int g = lane >> 4;
@@ -154,11 +177,19 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
             float gl[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) gl[j] = gelu_erf(v[j]);
+            if (CAN_DROP && ep.drop_thi) {
+                drop_run<8>(gl, (uint32_t)o_lo, ep);
+                drop_run<8>(gl + 8, (uint32_t)o_hi, ep);
+            }
             u32x4_t glo = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3]), pack_bf16x2(gl[4], gl[5]), pack_bf16x2(gl[6], gl[7])};
             u32x4_t ghi = {pack_bf16x2(gl[8], gl[9]), pack_bf16x2(gl[10], gl[11]), pack_bf16x2(gl[12], gl[13]), pack_bf16x2(gl[14], gl[15])};
             *(u32x4_t*)((bf16_t*)ep.out2 + o_lo) = glo;
             *(u32x4_t*)((bf16_t*)ep.out2 + o_hi) = ghi;
         } else if (EPI == VA_EPI_F32) {
+            if (CAN_DROP && ep.drop_thi) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) drop_run<4>(v + 4 * a, (uint32_t)((size_t)m * ldc + col(a)), ep);
+            }
             if (ep.resid != nullptr) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -180,6 +211,10 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
                 r[2 * j + 1] = v[2 * j + 1] * gelu_erf_grad(__uint_as_float(p_lo[j] & 0xffff0000u));
                 r[8 + 2 * j] = v[8 + 2 * j] * gelu_erf_grad(__uint_as_float(p_hi[j] << 16));
                 r[9 + 2 * j] = v[9 + 2 * j] * gelu_erf_grad(__uint_as_float(p_hi[j] & 0xffff0000u));
+            }
+            if (CAN_DROP && ep.drop_thi) {
+                drop_run<8>(r, (uint32_t)o_lo, ep);
+                drop_run<8>(r + 8, (uint32_t)o_hi, ep);
             }
             u32x4_t lo = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
             u32x4_t hi = {pack_bf16x2(r[8], r[9]), pack_bf16x2(r[10], r[11]), pack_bf16x2(r[12], r[13]), pack_bf16x2(r[14], r[15])};
@@ -707,8 +742,8 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         const bool full = cur.m0 + wm * 128 + 128 <= M;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            if (full) store_tile_wide<EPI, TM, true, HAS_BIAS, true>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
-            else store_tile_wide<EPI, TM, false, HAS_BIAS>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
+            if (full) store_tile_wide<EPI, TM, true, HAS_BIAS, true, false>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
+            else store_tile_wide<EPI, TM, false, HAS_BIAS, false, false>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
         }
         if (!more) break;
         post(before(slot), ticket);
@@ -854,9 +889,10 @@ int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, 
 
 }  // namespace
 
-extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
-                          int epilogue, void* out, void* out2, const float* bias, const float* resid,
-                          const void* aux, int64_t ldc, int tile, hipStream_t stream) {
+static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                         int epilogue, void* out, void* out2, const float* bias, const float* resid,
+                         const void* aux, int64_t ldc, int tile, uint32_t drop_key, uint32_t drop_thresh16,
+                         hipStream_t stream) {
     VA_CHECK_ARG(x && w && out, "va_gemm_nt: null operand");
     VA_CHECK_ARG(M > 0 && N > 0 && K > 0, "va_gemm_nt: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N,
                  (long long)K);
@@ -871,12 +907,14 @@ extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, in
         // per SIMD nothing overlaps an epilogue's transcendental math, so the GELU epilogues stay on the eight-wave
         // ring, whose two waves per SIMD cover each other's stalls.
         const bool big = N % 256 == 0 && M >= 2048 && K >= 128;
-        const bool quad = epilogue == VA_EPI_BF16 || epilogue == VA_EPI_F32;
+        const bool quad = epilogue == VA_EPI_BF16 || (epilogue == VA_EPI_F32 && drop_thresh16 == 0);
         tile = !big ? 128 : quad ? 4256 : 256;
     }
     VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || (tile >= 4256 && tile <= 4261)) && N % 256 == 0 && K >= 128),
                  "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
-    EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc};
+    VA_CHECK_ARG(drop_thresh16 == 0 || tile < 4256, "va_gemm_nt_dropout: the four-wave kernel (tile %d) has no dropout epilogue", tile);
+    EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc, drop_key, drop_thresh16 << 16,
+               va_drop_scale(drop_thresh16)};
     const bf16_t* X = (const bf16_t*)x;
     const bf16_t* W = (const bf16_t*)w;
     switch (epilogue) {
@@ -894,4 +932,25 @@ extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, in
             va_set_error("va_gemm_nt: unknown epilogue %d", epilogue);
             return VA_ERR_INVALID;
     }
+}
+
+extern "C" int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                          int epilogue, void* out, void* out2, const float* bias, const float* resid,
+                          const void* aux, int64_t ldc, int tile, hipStream_t stream) {
+    return gemm_nt_entry(x, w, M, N, K, ldx, ldw, epilogue, out, out2, bias, resid, aux, ldc, tile, 0u, 0u, stream);
+}
+
+extern "C" int va_gemm_nt_dropout(const void* x, const void* w, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                                  int64_t ldw, int epilogue, void* out, void* out2, const float* bias,
+                                  const float* resid, const void* aux, int64_t ldc, int tile, uint32_t key, float p,
+                                  hipStream_t stream) {
+    VA_CHECK_ARG(p >= 0.f && p < 1.f, "va_gemm_nt_dropout: dropout probability %g outside [0, 1)", (double)p);
+    const uint32_t thresh = va_drop_thresh16(p);
+    VA_CHECK_ARG(thresh < 65536u, "va_gemm_nt_dropout: dropout probability %g rounds to 1", (double)p);
+    if (thresh != 0) {
+        VA_CHECK_ARG(epilogue != VA_EPI_BF16, "va_gemm_nt_dropout: the plain bf16 epilogue has no dropout site");
+        VA_CHECK_ARG(ldc == N, "va_gemm_nt_dropout: the output must be contiguous (ldc == N): mask positions are m * N + n");
+        VA_CHECK_ARG(M * N < (1ll << 32), "va_gemm_nt_dropout: more than 2^32 output elements");
+    }
+    return gemm_nt_entry(x, w, M, N, K, ldx, ldw, epilogue, out, out2, bias, resid, aux, ldc, tile, key, thresh, stream);
 }

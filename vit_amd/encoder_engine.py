@@ -242,18 +242,12 @@ class EncoderEngine:
             ln2 = buf("ln2", D, BF16)
             ops.layernorm_fwd(x_mid, P[p + "norm2.weight"], P[p + "norm2.bias"], ln2, mean2, rstd2, LN_EPS)
             pre, act = buf("pre", 4 * D, BF16), buf("act", 4 * D, BF16)
+            # both MLP dropouts ride in the GEMM epilogues; the saved activation is the dropped one
             ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BIAS_GELU, pre, out2=act,
-                        bias=P[p + "mlp.0.bias"])
-            if p1 > 0:
-                ops.dropout(act, k1, p1)                 # in place: the saved activation is the dropped one
+                        bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
             x_next = buf("x_out", D, F32) if save else buf("x_out" + str(i & 1), D, F32)
-            if p2 > 0:
-                ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next,
-                            bias=P[p + "mlp.3.bias"])
-                ops.dropout(x_next, k2, p2, resid=x_mid)
-            else:
-                ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next,
-                            bias=P[p + "mlp.3.bias"], resid=x_mid)
+            ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next,
+                        bias=P[p + "mlp.3.bias"], resid=x_mid, drop_key=k2, drop_p=p2)
             if save:
                 ctx.blocks.append(_BlockSaved(x, mean1, rstd1, ln1, qkv, attn, lse2, x_mid, mean2, rstd2, ln2, pre, act))
             x = x_next
@@ -299,11 +293,16 @@ class EncoderEngine:
         d_wide = torch.empty(M, 4 * D, dtype=BF16, device=dev)    # d(pre-activation)
         dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
         drop = ctx.drop
-        g_drop = torch.empty(M, D, dtype=BF16, device=dev) if drop is not None else None   # dropped MLP-branch gradient
+
+        # The bf16 copy of the residual-stream gradient that enters block i from above is read only by block i's fc2
+        # gradient GEMMs, which sit behind the fc2 dropout: the kernel that writes the copy applies that mask.
+        def fc2_drop(i):
+            return (drop.keys[i][2], drop.p[i][2]) if drop is not None and i >= 0 else (0, 0.0)
 
         tail = carve([("norm.weight", (D,)), ("norm.bias", (D,))])
+        kd, pd = fc2_drop(cfg.depth - 1)
         ops.layernorm_bwd(gy, ctx.x_last, P["norm.weight"], ctx.mean_f, ctx.rstd_f, None, g_a, g_bf,
-                          grads["norm.weight"], grads["norm.bias"])
+                          grads["norm.weight"], grads["norm.bias"], drop_key=kd, drop_p=pd)
         if on_block_done is not None:
             on_block_done(tail)
         ctx.x_last = None
@@ -314,11 +313,10 @@ class EncoderEngine:
             flat = carve([(p + n, tuple(P[p + n].shape)) for n in BLOCK_PARAM_NAMES])
             pa, p1, p2 = drop.p[i] if drop is not None else (0.0, 0.0, 0.0)
             ka, k1, k2 = drop.keys[i] if drop is not None else (0, 0, 0)
-            # ---- MLP (the residual path keeps g_a / g_bf; only the branch gradient passes the fc2 dropout)
-            g_mlp = ops.dropout(g_bf, k2, p2, out=g_drop) if p2 > 0 else g_bf
-            ops.gemm_nt(g_mlp, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_GELU_BWD, d_wide, aux=s.pre)
-            if p1 > 0:
-                ops.dropout(d_wide, k1, p1)             # the mask commutes with the GELU derivative
+            # ---- MLP (g_bf arrives with the fc2 dropout's mask already applied; g_a is the undropped gradient)
+            g_mlp = g_bf
+            ops.gemm_nt(g_mlp, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_GELU_BWD, d_wide, aux=s.pre,
+                        drop_key=k1, drop_p=p1)       # the mask commutes with the GELU derivative
             ops.gemm_tn_accum(g_mlp, s.act, grads[p + "mlp.3.weight"], dbias=grads[p + "mlp.3.bias"])
             ops.gemm_nt(d_wide, Wc.bwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BF16, d_small)
             ops.gemm_tn_accum(d_wide, s.ln2, grads[p + "mlp.0.weight"], dbias=grads[p + "mlp.0.bias"])
@@ -331,8 +329,9 @@ class EncoderEngine:
             ops.rope3d_qk_(dqkv, tables, grid, inverse=True)
             ops.gemm_nt(dqkv, Wc.bwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, d_small)
             ops.gemm_tn_accum(dqkv, s.ln1, grads[p + "attn.qkv_proj.weight"])
+            kd, pd = fc2_drop(i - 1)
             ops.layernorm_bwd(d_small, s.x_in, P[p + "norm1.weight"], s.mean1, s.rstd1, g_b, g_a, g_bf,
-                              grads[p + "norm1.weight"], grads[p + "norm1.bias"])
+                              grads[p + "norm1.weight"], grads[p + "norm1.bias"], drop_key=kd, drop_p=pd)
             if on_block_done is not None:
                 on_block_done(flat)
             ctx.blocks[i] = None   # release this block's activations

@@ -39,8 +39,10 @@ def _ld(t: torch.Tensor) -> int:
 # ------------------------------------------------------------------ GEMMs
 def gemm_nt(x: torch.Tensor, w: torch.Tensor, epilogue: int, out: torch.Tensor, out2: Optional[torch.Tensor] = None,
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
-            aux: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
-    """out[M,N] = x[M,K] @ w[N,K]^T with a fused epilogue (see include/vit_amd.h)."""
+            aux: Optional[torch.Tensor] = None, tile: int = 0, drop_key: int = 0, drop_p: float = 0.0) -> torch.Tensor:
+    """out[M,N] = x[M,K] @ w[N,K]^T with a fused epilogue (see include/vit_amd.h).  drop_p > 0 applies the dropout
+    of `dropout(…, drop_key, drop_p)` inside the epilogue: to the GELU output (EPI_BIAS_GELU), to acc + bias before
+    the residual (EPI_F32), to the product with the GELU derivative (EPI_GELU_BWD)."""
     _need(x, BF16, "x"); _need(w, BF16, "w")
     M, K = x.shape
     N, K2 = w.shape
@@ -60,6 +62,11 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, epilogue: int, out: torch.Tensor, 
         if bias.numel() != N or not bias.is_contiguous():
             raise ValueError("gemm_nt: bias must be a contiguous [N] vector")
     lib = _lib.load()
+    if drop_p > 0:
+        check(lib.va_gemm_nt_dropout(_p(x), _p(w), M, N, K, _ld(x), _ld(w), epilogue, _p(out), _p(out2), _p(bias),
+                                     _p(resid), _p(aux), ldc, tile, drop_key & 0xFFFFFFFF, float(drop_p), _stream()),
+              "va_gemm_nt_dropout")
+        return out
     check(lib.va_gemm_nt(_p(x), _p(w), M, N, K, _ld(x), _ld(w), epilogue, _p(out), _p(out2), _p(bias), _p(resid),
                          _p(aux), ldc, tile, _stream()), "va_gemm_nt")
     return out
@@ -141,7 +148,9 @@ def layernorm_fwd(x, gamma, beta, out, mean, rstd, eps: float = 1e-6):
     return out
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, dgamma, dbeta):
+def layernorm_bwd(dy, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, dgamma, dbeta, drop_key: int = 0,
+                  drop_p: float = 0.0):
+    """drop_p > 0: dx_bf16 receives dropout(dx_out; drop_key, drop_p) instead of a plain bf16 copy."""
     _need(x, F32, "x"); _need(dx_out, F32, "dx_out"); _need(dgamma, F32, "dgamma"); _need(dbeta, F32, "dbeta")
     M, D = x.shape
     if dy.dtype not in (BF16, F32) or tuple(dy.shape) != (M, D) or not dy.is_contiguous():
@@ -156,6 +165,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, dgamma,
     lib = _lib.load()
     rows = lib.va_layernorm_bwd_partial_rows(M)
     partial = torch.empty(rows * 2 * D, dtype=F32, device=x.device)
+    if drop_p > 0:
+        check(lib.va_layernorm_bwd_dropout(_p(dy), int(dy.dtype == BF16), _p(x), _p(gamma), _p(mean), _p(rstd),
+                                           _p(resid_grad), _p(dx_out), _p(dx_bf16), _p(partial), _p(dgamma), _p(dbeta),
+                                           M, D, drop_key & 0xFFFFFFFF, float(drop_p), _stream()),
+              "va_layernorm_bwd_dropout")
+        return dx_out
     check(lib.va_layernorm_bwd(_p(dy), int(dy.dtype == BF16), _p(x), _p(gamma), _p(mean), _p(rstd), _p(resid_grad),
                                _p(dx_out), _p(dx_bf16), _p(partial), _p(dgamma), _p(dbeta), M, D, _stream()),
           "va_layernorm_bwd")
