@@ -220,7 +220,7 @@ def attn_reference(qkv, B, N, H):
 
 
 @pytest.mark.parametrize("B,N,H", [(2, 8, 16), (1, 200, 16), (2, 1568, 16), (1, 2048, 16), (2, 18, 8), (1, 300, 8),
-                                   (1, 1024, 8)])
+                                   (1, 1024, 8), (1, 8192, 16), (1, 8200, 8)])   # the last two: 64-frame clips
 def test_attention_fwd_bwd(ops, dev, B, N, H):
     D = 1024
     qkv = rnd((B * N, 3 * D), dev, 11, dtype=BF16)
