@@ -156,3 +156,10 @@ def test_frozen_encoder_and_world_model_forward(swm):
         p.requires_grad_(False)
     feats = m.encode_video(video)
     assert not feats.requires_grad
+
+
+def test_empty_batch(swm):
+    """No clips: an empty (0, N, D) result, as nn.Conv3d and the blocks give for an empty batch in the reference."""
+    enc = build(swm, 1, 16, 4, 32)
+    y = enc(torch.zeros(0, 3, 4, 32, 32, device="cuda"))
+    assert tuple(y.shape) == (0, 8, 1024) and y.dtype == torch.float32

@@ -222,6 +222,11 @@ class VideoViTEncoder(nn.Module):
     def forward(self, video: torch.Tensor) -> torch.Tensor:
         if not video.is_cuda:
             raise VitAmdError("VideoViTEncoder.forward needs a HIP device tensor: vit_amd has no CPU fallback")
+        if video.dim() == 5 and video.shape[0] == 0:
+            # an empty batch has nothing to launch; the reference returns an empty (0, N, D) tensor here as well
+            tt, th, tw = self._cfg.tubelet
+            n_tok = (video.shape[2] // tt) * (video.shape[3] // th) * (video.shape[4] // tw)
+            return video.new_zeros((0, n_tok, self._cfg.dim), dtype=torch.float32)
         named = dict(self.named_parameters())
         params = [named[n] for n in self._param_order]
         for n, p in zip(self._param_order, params):
