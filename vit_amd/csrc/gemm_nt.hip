@@ -906,7 +906,10 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
         // Large problems: the four-wave persistent kernel for the plain 2-byte and the f32 outputs.  With one wave
         // per SIMD nothing overlaps an epilogue's transcendental math, so the GELU epilogues stay on the eight-wave
         // ring, whose two waves per SIMD cover each other's stalls.
-        const bool big = N % 256 == 0 && M >= 2048 && K >= 128;
+        // ... and only when the 256-wide tiles fill most of the chip: a problem with few of them (small batches)
+        // spreads over four times as many workgroups with the 128-wide tile.
+        const int64_t tiles256 = ((M + 255) / 256) * (N / 256);
+        const bool big = N % 256 == 0 && M >= 2048 && K >= 128 && tiles256 >= 150;
         const bool quad = epilogue == VA_EPI_BF16 || (epilogue == VA_EPI_F32 && drop_thresh16 == 0);
         tile = !big ? 128 : quad ? 4256 : 256;
     }
