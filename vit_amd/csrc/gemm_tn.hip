@@ -419,6 +419,10 @@ extern "C" int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_
         int split = split_k;
         if (split == 0) {
             split = rtiles >= 256 ? 1 : 256 / rtiles;
+            // every slice adds a whole f32 tile into dW: with few rows per slice that traffic outweighs the
+            // contraction, so a short M is cut into fewer, longer slices (about 48 stages at least)
+            const int by_len = (int)(rstages / 48);
+            if (split > by_len) split = by_len;
             if (split < 1) split = 1;
         }
         int64_t per = (rstages + split - 1) / split;          // stages per slice
