@@ -364,10 +364,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// neg_delta[bh][n] = -mul * sum_d dO * O      (one 8-lane group per (token, head) for HD=64, 16 lanes for 128)
-// Also writes, per (bh, n), the 16-byte record the dK/dV pass feeds to the matrix pipe: -lse2 and -delta,
-// each split exactly into three bf16 terms {hi, mid | lo, 0} (8+8+8 mantissa bits), laid out as the first
-// two dwords of an MFMA operand fragment.
+// x split exactly into three bf16 terms {hi, mid | lo, 0} (8+8+8 mantissa bits), laid out as the first two
+// dwords of an MFMA operand fragment: how -lse2 and -delta of a query reach the dK/dV pass (see there).
 // ------------------------------------------------------------------------------------------------
 VA_DEVINL void split3_bf16(float x, uint32_t& d0, uint32_t& d1) {
     const uint32_t hi = __float_as_uint(x) & 0xffff0000u;
@@ -378,55 +376,21 @@ VA_DEVINL void split3_bf16(float x, uint32_t& d0, uint32_t& d1) {
     d1 = __float_as_uint(lo) >> 16;    // at most 8 significant bits are left: exact
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ DO,
-                                                         const float* __restrict__ LSE2, float* __restrict__ neg_delta,
-                                                         u32x4_t* __restrict__ aux, int64_t rows, int N, int H,
-                                                         int64_t ldo, float mul) {
-    constexpr int LPH = HD / 8;   // lanes per (row, head)
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t item = gid / LPH;             // (row, head)
-    const int part = (int)(gid % LPH);
-    float s = 0.f;
-    const bool live = item < rows * H;
-    const int64_t row = live ? item / H : 0;
-    const int hh = live ? (int)(item % H) : 0;
-    if (live) {
-        const u32x4_t a = *(const u32x4_t*)(O + row * ldo + hh * HD + part * 8);
-        const u32x4_t d = *(const u32x4_t*)(DO + row * ldo + hh * HD + part * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s += __uint_as_float(a[j] << 16) * __uint_as_float(d[j] << 16);
-            s += __uint_as_float(a[j] & 0xffff0000u) * __uint_as_float(d[j] & 0xffff0000u);
-        }
-    }
-#pragma unroll
-    for (int off = LPH / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (live && part == 0) {
-        const int64_t b = row / N, n = row % N;
-        const int64_t at = (b * H + hh) * N + n;
-        s *= mul;              // 1, or (1 - p) when the passes fold the dropout rescale into their output factor
-        neg_delta[at] = -s;
-        u32x4_t rec;
-        uint32_t d0, d1;
-        split3_bf16(-LSE2[at], d0, d1);
-        rec[0] = d0; rec[1] = d1;
-        split3_bf16(-s, d0, d1);
-        rec[2] = d0; rec[3] = d1;
-        aux[at] = rec;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// dQ pass: query-stationary, streams K and V.
+// dQ pass: query-stationary, streams K and V.  It also produces what both backward passes need per query:
+// delta = sum_d dO * O (each lane already holds half of its query's dO row; the O row is read the same way), kept
+// as -mul * delta (mul = 1, or 1 - p when the dropout rescale is folded into the output factors), written to
+// NEG_DELTA and, together with -lse2, as the 16-byte record the dK/dV pass feeds to the matrix pipe.
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool RAGGED, bool DROP = false>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
+                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
+                                                          const bf16_t* __restrict__ DO,
                                                           const float* __restrict__ LSE2,
-                                                          const float* __restrict__ NEG_DELTA, bf16_t* __restrict__ DQ,
-                                                          int N, int H, int64_t ld, int64_t ldo, int64_t lddq, float c,
-                                                          float scale, DropArgs drop) {
+                                                          float* __restrict__ NEG_DELTA, u32x4_t* __restrict__ AUX,
+                                                          bf16_t* __restrict__ DQ, int N, int H, int64_t ld,
+                                                          int64_t ldo, int64_t lddq, float c, float scale, float mul,
+                                                          DropArgs drop) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -449,7 +413,33 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
     // A lane holds one query's column of every score tile, so -lse and -delta are per-lane constants: the
     // score / dP accumulators start from them and the MFMA chains deliver s*c - lse and dP - delta directly.
     const float lse = LSE2[(int64_t)bh * N + qrow_c];
-    const float ndl = NEG_DELTA[(int64_t)bh * N + qrow_c];
+    float dot = 0.f;
+    {
+        const bf16_t* orow = O + ((int64_t)b * N + qrow_c) * ldo + hh * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4_t ov = *(const u32x4_t*)(orow + ks * 16 + h * 8);
+            const u32x4_t dv = __builtin_bit_cast(u32x4_t, dof[ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dot += __uint_as_float(ov[j] << 16) * __uint_as_float(dv[j] << 16);
+                dot += __uint_as_float(ov[j] & 0xffff0000u) * __uint_as_float(dv[j] & 0xffff0000u);
+            }
+        }
+    }
+    dot += __shfl_xor(dot, 32);                 // the other half of the row sits in the partner half-lane
+    const float ndl = -(dot * mul);
+    if (h == 0 && qrow < N) {
+        const int64_t at = (int64_t)bh * N + qrow;
+        NEG_DELTA[at] = ndl;
+        u32x4_t rec;
+        uint32_t d0, d1;
+        split3_bf16(-lse, d0, d1);
+        rec[0] = d0; rec[1] = d1;
+        split3_bf16(ndl, d0, d1);
+        rec[2] = d0; rec[3] = d1;
+        AUX[at] = rec;
+    }
     f32x16_t neg_lse, neg_dl;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { neg_lse[i] = -lse; neg_dl[i] = ndl; }
@@ -758,16 +748,12 @@ int bwd_launch_as(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_
     const float scale = 1.0f / sqrtf((float)HD);
     const float c = 1.4426950408889634f * scale;
     const int64_t rows = (int64_t)B * N;
-    const int64_t threads = rows * H * (HD / 8);
-    // workspace: [B*H*N] 16-byte records for the dK/dV pass, then [B*H*N] f32 -delta
+    // workspace: [B*H*N] 16-byte records for the dK/dV pass, then [B*H*N] f32 -delta; both written by the dQ pass
     u32x4_t* aux = (u32x4_t*)workspace;
     float* delta = workspace + 4 * rows * H;
-    hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, o, d_o,
-                       lse2, delta, aux, rows, N, H, ldo, DROP ? 1.0f / drop.scale : 1.0f);
-    VA_CHECK_LAUNCH("va_attn_bwd(delta)");
     const dim3 grid((N + 127) / 128, B * H);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, RAGGED, DROP>), grid, dim3(256), LDS_DQ, stream, q, k, v, d_o, lse2,
-                       delta, dq, N, H, ld, ldo, lddq, c, scale, drop);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, RAGGED, DROP>), grid, dim3(256), LDS_DQ, stream, q, k, v, o, d_o, lse2,
+                       delta, aux, dq, N, H, ld, ldo, lddq, c, scale, DROP ? 1.0f / drop.scale : 1.0f, drop);
     VA_CHECK_LAUNCH("va_attn_bwd(dq)");
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, RAGGED_DKV, DROP>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux, delta,
                        dk, dv, N, H, ld, ldo, lddq, c, scale, drop);
