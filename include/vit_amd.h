@@ -159,6 +159,18 @@ int va_dropout(const void* in, int in_bf16, void* out, int out_bf16, const float
 int va_cast_f32_bf16(const float* src, void* dst, int64_t n, va_stream_t stream);
 /* w f32 [R,C] -> wt bf16 [C,R] (transposed operand for the data-gradient GEMMs). R,C % 32 == 0. */
 int va_cast_transpose_f32_bf16(const float* w, void* wt, int64_t R, int64_t C, va_stream_t stream);
+/* Both copies of many matrices in one launch (all weights of a model after an optimizer step).  `jobs` is a DEVICE
+ * array; job i covers tiles [first_tile, first_tile + rows/64 * cols/64) of the launch, first_tile ascending from 0;
+ * rows, cols % 64 == 0; dst (bf16 [rows, cols]) and dst_t (bf16 [cols, rows]) may each be null.  The caller
+ * validates the jobs: the library only sees the device copy. */
+typedef struct va_cast_job {
+    const float* src;
+    void* dst;
+    void* dst_t;
+    int32_t rows, cols;
+    int64_t first_tile;
+} va_cast_job;
+int va_multi_cast_f32_bf16(const va_cast_job* jobs, int64_t njobs, int64_t total_tiles, va_stream_t stream);
 
 /* ---- token masking ------------------------------------------------------------------------------------
  * Deterministic future masking (s1:300-333): rows n >= cutoff*(N/Tp) of every batch item are zeroed,

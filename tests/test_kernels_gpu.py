@@ -375,3 +375,24 @@ def test_normalize_u8_bit_exact(ops, dev, B, T, H, W):
     frames[0, 0, 0, 0] = torch.tensor([0, 255, 128], dtype=torch.uint8)
     out = ops.normalize_u8(frames.to(dev))
     assert torch.equal(out.cpu(), R.normalize_u8(frames))
+
+
+def test_multi_cast_plan(ops, dev):
+    """Several matrices, one launch: both copies bit-identical to torch's rounding; null destinations skipped."""
+    shapes = [(64, 64), (1024, 1536), (192, 4096), (3072, 1024)]
+    srcs = [rnd(sh, dev, 70 + i) for i, sh in enumerate(shapes)]
+    dst = [torch.zeros(sh, dtype=BF16, device=dev) for sh in shapes]
+    dst_t = [torch.zeros(sh[::-1], dtype=BF16, device=dev) for sh in shapes]
+    dst[2], dst_t[1] = None, None
+    plan = ops.CastPlan(list(zip(srcs, dst, dst_t)))
+    plan.run()
+    for s_, d, t in zip(srcs, dst, dst_t):
+        if d is not None:
+            assert torch.equal(d, s_.to(BF16))
+        if t is not None:
+            assert torch.equal(t, s_.t().contiguous().to(BF16))
+    srcs[0].mul_(2.0)
+    plan.run()                                   # same plan, new values
+    assert torch.equal(dst[0], srcs[0].to(BF16)) and torch.equal(dst_t[0], srcs[0].t().contiguous().to(BF16))
+    with pytest.raises(ValueError):
+        ops.CastPlan([(rnd((100, 64), dev, 1), None, None)])

@@ -46,6 +46,7 @@ SIGNATURES = {
     "va_dropout": (ci, [vp, ci, vp, ci, vp, i64, cu32, cf, vp]),
     "va_cast_f32_bf16": (ci, [vp, vp, i64, vp]),
     "va_cast_transpose_f32_bf16": (ci, [vp, vp, i64, i64, vp]),
+    "va_multi_cast_f32_bf16": (ci, [vp, i64, i64, vp]),
     "va_future_mask": (ci, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "va_token_gather": (ci, [vp, vp, vp, i64, i64, i64, i64, vp]),
     "va_token_scatter": (ci, [vp, vp, vp, i64, i64, i64, i64, vp]),

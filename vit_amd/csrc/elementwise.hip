@@ -294,6 +294,46 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     for (int j = 0; j < 4; ++j) wt[(int64_t)(c0 + ty + 8 * j) * R + r0 + tx] = f32_to_bf16(tile[tx][ty + 8 * j]);
 }
 
+// Many matrices in one launch: every f32 [rows, cols] source gets a bf16 copy and (optionally) a bf16 transposed
+// copy from ONE read.  A block handles one 64 x 64 tile; it finds its matrix by bisecting the jobs' first-tile
+// numbers.  Loads and both stores move 128 or 256 contiguous bytes per 16 lanes; the transpose goes through LDS.
+__global__ __launch_bounds__(256) void multi_cast_kernel(const va_cast_job* __restrict__ jobs, int njobs) {
+    __shared__ float tile[64][65];
+    const int64_t b = blockIdx.x;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                      // last job whose first_tile <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_tile <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const va_cast_job job = jobs[lo];
+    const int tiles_c = job.cols / 64;
+    const int64_t local = b - job.first_tile;
+    const int r0 = (int)(local / tiles_c) * 64, c0 = (int)(local % tiles_c) * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    bf16_t* dst = (bf16_t*)job.dst;
+    bf16_t* dst_t = (bf16_t*)job.dst_t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = ty + 16 * k;
+        const f32x4_t v = *(const f32x4_t*)(job.src + (int64_t)(r0 + r) * job.cols + c0 + tx * 4);
+        if (dst != nullptr)
+            *(u32x2_t*)(dst + (int64_t)(r0 + r) * job.cols + c0 + tx * 4) = (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (dst_t != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[r][tx * 4 + j] = v[j];
+        }
+    }
+    if (dst_t == nullptr) return;          // uniform over the block
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = ty + 16 * k;         // source column = destination row
+        const u32x2_t pk = {pack_bf16x2(tile[tx * 4][c], tile[tx * 4 + 1][c]), pack_bf16x2(tile[tx * 4 + 2][c], tile[tx * 4 + 3][c])};
+        *(u32x2_t*)(dst_t + (int64_t)(c0 + c) * job.rows + r0 + tx * 4) = pk;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // column sums of a bf16 matrix (bias gradients): block = 64 column groups (8 cols each) x 4 row lanes.
 // ------------------------------------------------------------------------------------------------
@@ -603,6 +643,14 @@ extern "C" int va_cast_f32_bf16(const float* src, void* dst, int64_t n, hipStrea
     VA_CHECK_ARG(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "va_cast_f32_bf16: misaligned operand");
     hipLaunchKernelGGL(cast_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, stream, src, (bf16_t*)dst, n);
     VA_CHECK_LAUNCH("va_cast_f32_bf16");
+    return VA_OK;
+}
+
+extern "C" int va_multi_cast_f32_bf16(const va_cast_job* jobs, int64_t njobs, int64_t total_tiles, hipStream_t stream) {
+    VA_CHECK_ARG(jobs && njobs > 0 && njobs < (1 << 20), "va_multi_cast_f32_bf16: empty or oversized job list");
+    VA_CHECK_ARG(total_tiles > 0 && total_tiles < (1ll << 31), "va_multi_cast_f32_bf16: bad tile count %lld", (long long)total_tiles);
+    hipLaunchKernelGGL(multi_cast_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, jobs, (int)njobs);
+    VA_CHECK_LAUNCH("va_multi_cast_f32_bf16");
     return VA_OK;
 }
 

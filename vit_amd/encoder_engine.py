@@ -71,6 +71,8 @@ class WeightCache:
     def __init__(self):
         self._fwd: Dict[str, Tuple[int, int, torch.Tensor]] = {}
         self._bwd: Dict[str, Tuple[int, int, torch.Tensor]] = {}
+        self._plan_key = None
+        self._plan = None
 
     @staticmethod
     def _key(p: torch.Tensor):
@@ -80,6 +82,40 @@ class WeightCache:
         """Forget which parameter versions the copies were made from (the buffers are kept and reused)."""
         self._fwd = {k: (0, -1, v[2]) for k, v in self._fwd.items()}
         self._bwd = {k: (0, -1, v[2]) for k, v in self._bwd.items()}
+
+    def prepare(self, items, transposed: bool) -> None:
+        """Refresh, in ONE launch, the copies of every listed (name, parameter) that changed since they were made
+        (after an optimizer step: all of them).  fwd() / bwd() then find them current; whatever is not handled
+        here (sides that are not multiples of 64) is still made on first use."""
+        jobs = []
+        for name, p in items:
+            key = self._key(p)
+            f, b = self._fwd.get(name), self._bwd.get(name)
+            need_f = f is None or (f[0], f[1]) != key
+            need_b = transposed and (b is None or (b[0], b[1]) != key)
+            w2d = p.detach().reshape(p.shape[0], -1)
+            if not (need_f or need_b) or w2d.shape[0] % 64 or w2d.shape[1] % 64 or not w2d.is_contiguous():
+                continue
+            R, C = w2d.shape
+            fbuf = bbuf = None
+            if need_f:
+                fbuf = f[2] if f is not None and tuple(f[2].shape) == (R, C) else torch.empty(R, C, dtype=BF16, device=p.device)
+            if need_b:
+                bbuf = b[2] if b is not None and tuple(b[2].shape) == (C, R) else torch.empty(C, R, dtype=BF16, device=p.device)
+            jobs.append((name, key, w2d, fbuf, bbuf))
+        if not jobs:
+            return
+        plan_key = tuple((n, w.data_ptr(), None if f is None else f.data_ptr(), None if b is None else b.data_ptr())
+                         for n, _, w, f, b in jobs)
+        if plan_key != self._plan_key:
+            self._plan = ops.CastPlan([(w, f, b) for _, _, w, f, b in jobs])
+            self._plan_key = plan_key
+        self._plan.run()
+        for name, key, _, fbuf, bbuf in jobs:
+            if fbuf is not None:
+                self._fwd[name] = (*key, fbuf)
+            if bbuf is not None:
+                self._bwd[name] = (*key, bbuf)
 
     def fwd(self, name: str, p: torch.Tensor) -> torch.Tensor:
         ent = self._fwd.get(name)
@@ -194,6 +230,13 @@ class EncoderEngine:
 
         def new(cols, dtype):
             return torch.empty(M, cols, dtype=dtype, device=dev)
+
+        weight_items = [("pe", P["tubelet_embed.projection.weight"])]
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            weight_items += [(p + "qkv", P[p + "attn.qkv_proj.weight"]), (p + "out", P[p + "attn.out_proj.weight"]),
+                             (p + "fc1", P[p + "mlp.0.weight"]), (p + "fc2", P[p + "mlp.3.weight"])]
+        Wc.prepare(weight_items, transposed=save)
 
         patches = ops.tubelet_gather(video, cfg.tubelet)
         x = new(D, F32)

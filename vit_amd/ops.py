@@ -326,6 +326,39 @@ def cast_transpose_bf16(w: torch.Tensor, dst: Optional[torch.Tensor] = None) -> 
     return dst
 
 
+class CastPlan:
+    """A fixed list of (f32 matrix -> bf16 copy [, bf16 transposed copy]) jobs executed by one launch.  The job
+    table lives on the device; build a new plan when a source or destination buffer moves."""
+
+    def __init__(self, triples):
+        """triples: (src f32 [R,C] contiguous, dst bf16 [R,C] or None, dst_t bf16 [C,R] or None), R, C % 64 == 0."""
+        import struct
+        rec, first = [], 0
+        self._keep = []
+        for src, dst, dst_t in triples:
+            _need(src, F32, "src")
+            if src.dim() != 2 or not src.is_contiguous() or src.shape[0] % 64 or src.shape[1] % 64:
+                raise ValueError("CastPlan: sources must be contiguous matrices with sides that are multiples of 64")
+            R, C = src.shape
+            for t, shp, nm in ((dst, (R, C), "dst"), (dst_t, (C, R), "dst_t")):
+                if t is not None:
+                    _need(t, BF16, nm)
+                    if tuple(t.shape) != shp or not t.is_contiguous() or t.device != src.device:
+                        raise ValueError(f"CastPlan: {nm} must be a contiguous bf16 {shp} tensor on the source's device")
+            rec.append(struct.pack("<QQQiiq", src.data_ptr(), _p(dst) or 0, _p(dst_t) or 0, R, C, first))
+            first += (R // 64) * (C // 64)
+            self._keep.append((src, dst, dst_t))
+        if not rec:
+            raise ValueError("CastPlan: no jobs")
+        self.njobs, self.tiles = len(rec), first
+        blob = torch.frombuffer(bytearray(b"".join(rec)), dtype=torch.uint8)
+        self._table = blob.to(self._keep[0][0].device)
+
+    def run(self) -> None:
+        check(_lib.load().va_multi_cast_f32_bf16(_p(self._table), self.njobs, self.tiles, _stream()),
+              "va_multi_cast_f32_bf16")
+
+
 # ------------------------------------------------------------------ input pipeline
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
