@@ -92,12 +92,14 @@ int64_t va_layernorm_bwd_partial_rows(int64_t M);
 int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
                      const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16, float* partial,
                      float* dgamma, float* dbeta, int64_t M, int64_t D, va_stream_t stream);
-/* The same, with dx_bf16 = va_dropout(dx_out; key, p) instead of a plain copy: the bf16 copy is the operand of the
- * gradient GEMMs of a branch that sits behind an nn.Dropout (swm:702); dx_out itself stays undropped. */
+/* The same with two optional extras for the bf16 copy, which is the operand of the gradient GEMMs of the linear layer
+ * above (swm:701-702): p > 0 makes it va_dropout(dx_out; key, p) instead of a plain copy (dx_out itself stays
+ * undropped), and copy_colsum [D] f32 (nullable) receives its column sums = that layer's bias gradient.  With
+ * copy_colsum the workspace is va_layernorm_bwd_partial_rows(M) * 3 * D floats. */
 int va_layernorm_bwd_dropout(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
                              const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16, float* partial,
                              float* dgamma, float* dbeta, int64_t M, int64_t D, uint32_t key, float p,
-                             va_stream_t stream);
+                             float* copy_colsum, va_stream_t stream);
 
 /* ---- 3D rotary embedding (swm:33-51, 265-281) ------------------------------------------------------
  * In-place rotation of the Q and K thirds of a packed qkv buffer [M, 3*D] bf16 (D = 1024, column

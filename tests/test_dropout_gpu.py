@@ -147,6 +147,15 @@ def test_layernorm_bwd_dropped_copy(ops, dev):
     assert torch.equal(dxb0, dx0.to(BF16))
     mask = R.drop_mask(key, (M, D), p).to(dev)
     assert torch.equal(dxb1, (dx0 * mask).to(BF16))
+    # column sums of the copy (the bias gradient of the layer whose gradient GEMMs read it), with and without a mask
+    for kw, copy in (({}, dxb0), ({"drop_key": key, "drop_p": p}, dxb1)):
+        dx, dxb = torch.empty(M, D, dtype=F32, device=dev), torch.empty(M, D, dtype=BF16, device=dev)
+        dg, db = torch.empty(D, dtype=F32, device=dev), torch.empty(D, dtype=F32, device=dev)
+        cs = torch.full((D,), 7.0, dtype=F32, device=dev)
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, resid, dx, dxb, dg, db, copy_colsum=cs, **kw)
+        assert torch.equal(dxb, copy) and torch.equal(dg, dg0) and torch.equal(db, db0)
+        want = copy.double().sum(0)
+        assert (cs.double() - want).abs().max().item() <= 1e-5 * copy.double().abs().sum(0).max().item()
 
 
 # ------------------------------------------------------------------------------ attention

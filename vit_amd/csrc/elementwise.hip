@@ -83,15 +83,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ resid_grad, float* __restrict__ dx_out,
                                                      bf16_t* __restrict__ dx_bf16, float* __restrict__ partial,
-                                                     int64_t M, uint32_t drop_key, uint32_t drop_thi, float drop_scale) {
-    __shared__ float red[2][4][LN_D];
+                                                     int64_t M, uint32_t drop_key, uint32_t drop_thi, float drop_scale,
+                                                     int nsets) {
+    // nsets = 3: besides dgamma / dbeta the column sums of the bf16 copy are produced (the bias gradient of the
+    // linear layer whose gradient GEMMs read that copy)
+    __shared__ float red[3][4][LN_D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4_t gm[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) gm[g] = *(const f32x4_t*)(gamma + g * 256 + lane * 4);
-    float dg[16], db[16];
+    float dg[16], db[16], dc[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { dg[i] = 0.f; db[i] = 0.f; dc[i] = 0.f; }
 
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -146,7 +149,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                         o[2 * q + 1] = drop_keep_odd(hsh, drop_thi) ? __fmul_rn(o[2 * q + 1], drop_scale) : 0.f;
                     }
                 }
-                *(u32x2_t*)(dx_bf16 + row * LN_D + c) = (u32x2_t){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                const u32x2_t pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                *(u32x2_t*)(dx_bf16 + row * LN_D + c) = pk;
+                if (nsets == 3) {   // sums of the ROUNDED values: what a GEMM over the copy would add up
+                    dc[4 * g + 0] += __uint_as_float(pk[0] << 16); dc[4 * g + 1] += __uint_as_float(pk[0] & 0xffff0000u);
+                    dc[4 * g + 2] += __uint_as_float(pk[1] << 16); dc[4 * g + 3] += __uint_as_float(pk[1] & 0xffff0000u);
+                }
             }
         }
     }
@@ -156,30 +164,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         for (int j = 0; j < 4; ++j) {
             red[0][wave][g * 256 + lane * 4 + j] = dg[4 * g + j];
             red[1][wave][g * 256 + lane * 4 + j] = db[4 * g + j];
+            if (nsets == 3) red[2][wave][g * 256 + lane * 4 + j] = dc[4 * g + j];
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < LN_D; c += 256) {
-        partial[((int64_t)blockIdx.x * 2 + 0) * LN_D + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        partial[((int64_t)blockIdx.x * 2 + 1) * LN_D + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    }
+    for (int c = threadIdx.x; c < LN_D; c += 256)
+        for (int w = 0; w < nsets; ++w)
+            partial[((int64_t)blockIdx.x * nsets + w) * LN_D + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
 }
 
-// dgamma[c] = sum_b partial[b][0][c], dbeta[c] = sum_b partial[b][1][c].  Block = 16 columns x 16 row
-// lanes; grid = 2 * D / 16 blocks (first half dgamma, second half dbeta).
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// dgamma[c] = sum_b partial[b][0][c], dbeta[c] = sum_b partial[b][1][c], colsum[c] = sum_b partial[b][2][c].
+// Block = 16 columns x 16 row lanes; grid = nsets * D / 16 blocks (one run of blocks per output).
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int nsets,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ colsum) {
     __shared__ float red[16][17];
     const int which = blockIdx.x / (LN_D / 16);
     const int c = (blockIdx.x % (LN_D / 16)) * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
     float a = 0.f;
-    for (int r = part; r < nblk; r += 16) a += partial[((int64_t)r * 2 + which) * LN_D + c];
+    for (int r = part; r < nblk; r += 16) a += partial[((int64_t)r * nsets + which) * LN_D + c];
     red[part][threadIdx.x & 15] = a;
     __syncthreads();
     if (part == 0) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
-        (which == 0 ? dgamma : dbeta)[c] = t;
+        (which == 0 ? dgamma : which == 1 ? dbeta : colsum)[c] = t;
     }
 }
 
@@ -566,13 +575,15 @@ extern "C" int64_t va_layernorm_bwd_partial_rows(int64_t M) {
 extern "C" int va_layernorm_bwd_dropout(const void* dy, int dy_bf16, const float* x, const float* gamma,
                                         const float* mean, const float* rstd, const float* resid_grad, float* dx_out,
                                         void* dx_bf16, float* partial, float* dgamma, float* dbeta, int64_t M,
-                                        int64_t D, uint32_t key, float p, hipStream_t stream) {
+                                        int64_t D, uint32_t key, float p, float* copy_colsum, hipStream_t stream) {
     VA_CHECK_ARG(p >= 0.f && p < 1.f, "va_layernorm_bwd: dropout probability %g outside [0, 1)", (double)p);
     const uint32_t thresh = va_drop_thresh16(p);
     VA_CHECK_ARG(thresh < 65536u, "va_layernorm_bwd: dropout probability %g rounds to 1", (double)p);
     VA_CHECK_ARG(thresh == 0 || (dx_bf16 && M * D < (1ll << 32)), "va_layernorm_bwd: dropout needs the bf16 output and fewer than 2^32 elements");
+    VA_CHECK_ARG(!copy_colsum || dx_bf16, "va_layernorm_bwd: column sums of the bf16 copy need the bf16 copy");
     const uint32_t thi = thresh << 16;
     const float dscale = va_drop_scale(thresh);
+    const int nsets = copy_colsum ? 3 : 2;
     VA_CHECK_ARG(dy && x && gamma && mean && rstd && dx_out && partial && dgamma && dbeta, "va_layernorm_bwd: null operand");
     VA_CHECK_ARG(D == LN_D, "va_layernorm_bwd: width %lld not supported (the encoder is 1024 wide)", (long long)D);
     VA_CHECK_ARG(M > 0, "va_layernorm_bwd: empty input");
@@ -580,12 +591,13 @@ extern "C" int va_layernorm_bwd_dropout(const void* dy, int dy_bf16, const float
     const int nblk = (int)va_layernorm_bwd_partial_rows(M);
     if (dy_bf16)
         hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nblk), dim3(256), 0, stream, dy, x, gamma, mean, rstd, resid_grad,
-                           dx_out, (bf16_t*)dx_bf16, partial, M, key, thi, dscale);
+                           dx_out, (bf16_t*)dx_bf16, partial, M, key, thi, dscale, nsets);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nblk), dim3(256), 0, stream, dy, x, gamma, mean, rstd, resid_grad,
-                           dx_out, (bf16_t*)dx_bf16, partial, M, key, thi, dscale);
+                           dx_out, (bf16_t*)dx_bf16, partial, M, key, thi, dscale, nsets);
     VA_CHECK_LAUNCH("va_layernorm_bwd");
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(2 * LN_D / 16), dim3(256), 0, stream, partial, nblk, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(nsets * LN_D / 16), dim3(256), 0, stream, partial, nblk, nsets, dgamma,
+                       dbeta, copy_colsum);
     VA_CHECK_LAUNCH("va_layernorm_bwd(reduce)");
     return VA_OK;
 }
@@ -594,7 +606,7 @@ extern "C" int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, con
                                 const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16,
                                 float* partial, float* dgamma, float* dbeta, int64_t M, int64_t D, hipStream_t stream) {
     return va_layernorm_bwd_dropout(dy, dy_bf16, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, partial, dgamma, dbeta,
-                                    M, D, 0u, 0.f, stream);
+                                    M, D, 0u, 0.f, nullptr, stream);
 }
 
 extern "C" int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, int64_t Tp, int64_t Hp, int64_t Wp,

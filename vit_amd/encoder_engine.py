@@ -342,10 +342,18 @@ class EncoderEngine:
         def fc2_drop(i):
             return (drop.keys[i][2], drop.p[i][2]) if drop is not None and i >= 0 else (0, 0.0)
 
+        # ... and its column sums are that block's fc2 bias gradient, so the block's gradient buffer is carved one
+        # step ahead of its backward and the weight-gradient GEMM of fc2 runs without the bias sums.
+        def carve_block(i):
+            pre = f"blocks.{i}."
+            return carve([(pre + n, tuple(P[pre + n].shape)) for n in BLOCK_PARAM_NAMES])
+
         tail = carve([("norm.weight", (D,)), ("norm.bias", (D,))])
+        flat_next = carve_block(cfg.depth - 1) if cfg.depth > 0 else None
         kd, pd = fc2_drop(cfg.depth - 1)
         ops.layernorm_bwd(gy, ctx.x_last, P["norm.weight"], ctx.mean_f, ctx.rstd_f, None, g_a, g_bf,
-                          grads["norm.weight"], grads["norm.bias"], drop_key=kd, drop_p=pd)
+                          grads["norm.weight"], grads["norm.bias"], drop_key=kd, drop_p=pd,
+                          copy_colsum=grads[f"blocks.{cfg.depth - 1}.mlp.3.bias"] if cfg.depth > 0 else None)
         if on_block_done is not None:
             on_block_done(tail)
         ctx.x_last = None
@@ -353,14 +361,14 @@ class EncoderEngine:
         for i in reversed(range(cfg.depth)):
             p = f"blocks.{i}."
             s = ctx.blocks[i]
-            flat = carve([(p + n, tuple(P[p + n].shape)) for n in BLOCK_PARAM_NAMES])
+            flat = flat_next
             pa, p1, p2 = drop.p[i] if drop is not None else (0.0, 0.0, 0.0)
             ka, k1, k2 = drop.keys[i] if drop is not None else (0, 0, 0)
             # ---- MLP (g_bf arrives with the fc2 dropout's mask already applied; g_a is the undropped gradient)
             g_mlp = g_bf
             ops.gemm_nt(g_mlp, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_GELU_BWD, d_wide, aux=s.pre,
                         drop_key=k1, drop_p=p1)       # the mask commutes with the GELU derivative
-            ops.gemm_tn_accum(g_mlp, s.act, grads[p + "mlp.3.weight"], dbias=grads[p + "mlp.3.bias"])
+            ops.gemm_tn_accum(g_mlp, s.act, grads[p + "mlp.3.weight"])     # the bias gradient came with g_bf
             ops.gemm_nt(d_wide, Wc.bwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BF16, d_small)
             ops.gemm_tn_accum(d_wide, s.ln2, grads[p + "mlp.0.weight"], dbias=grads[p + "mlp.0.bias"])
             ops.layernorm_bwd(d_small, s.x_mid, P[p + "norm2.weight"], s.mean2, s.rstd2, g_a, g_b, g_bf,
@@ -373,8 +381,10 @@ class EncoderEngine:
             ops.gemm_nt(dqkv, Wc.bwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, d_small)
             ops.gemm_tn_accum(dqkv, s.ln1, grads[p + "attn.qkv_proj.weight"])
             kd, pd = fc2_drop(i - 1)
+            flat_next = carve_block(i - 1) if i > 0 else None
             ops.layernorm_bwd(d_small, s.x_in, P[p + "norm1.weight"], s.mean1, s.rstd1, g_b, g_a, g_bf,
-                              grads[p + "norm1.weight"], grads[p + "norm1.bias"], drop_key=kd, drop_p=pd)
+                              grads[p + "norm1.weight"], grads[p + "norm1.bias"], drop_key=kd, drop_p=pd,
+                              copy_colsum=grads[f"blocks.{i - 1}.mlp.3.bias"] if i > 0 else None)
             if on_block_done is not None:
                 on_block_done(flat)
             ctx.blocks[i] = None   # release this block's activations

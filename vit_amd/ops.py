@@ -149,8 +149,9 @@ def layernorm_fwd(x, gamma, beta, out, mean, rstd, eps: float = 1e-6):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, dgamma, dbeta, drop_key: int = 0,
-                  drop_p: float = 0.0):
-    """drop_p > 0: dx_bf16 receives dropout(dx_out; drop_key, drop_p) instead of a plain bf16 copy."""
+                  drop_p: float = 0.0, copy_colsum: Optional[torch.Tensor] = None):
+    """drop_p > 0: dx_bf16 receives dropout(dx_out; drop_key, drop_p) instead of a plain bf16 copy.
+    copy_colsum [D] f32: receives the column sums of dx_bf16 (overwritten)."""
     _need(x, F32, "x"); _need(dx_out, F32, "dx_out"); _need(dgamma, F32, "dgamma"); _need(dbeta, F32, "dbeta")
     M, D = x.shape
     if dy.dtype not in (BF16, F32) or tuple(dy.shape) != (M, D) or not dy.is_contiguous():
@@ -164,11 +165,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, dgamma,
         _need(dx_bf16, BF16, "dx_bf16")
     lib = _lib.load()
     rows = lib.va_layernorm_bwd_partial_rows(M)
-    partial = torch.empty(rows * 2 * D, dtype=F32, device=x.device)
-    if drop_p > 0:
+    if copy_colsum is not None:
+        _need(copy_colsum, F32, "copy_colsum")
+        if copy_colsum.numel() != D or not copy_colsum.is_contiguous() or dx_bf16 is None:
+            raise ValueError("layernorm_bwd: copy_colsum must be a contiguous [D] vector and needs dx_bf16")
+    partial = torch.empty(rows * (3 if copy_colsum is not None else 2) * D, dtype=F32, device=x.device)
+    if drop_p > 0 or copy_colsum is not None:
         check(lib.va_layernorm_bwd_dropout(_p(dy), int(dy.dtype == BF16), _p(x), _p(gamma), _p(mean), _p(rstd),
                                            _p(resid_grad), _p(dx_out), _p(dx_bf16), _p(partial), _p(dgamma), _p(dbeta),
-                                           M, D, drop_key & 0xFFFFFFFF, float(drop_p), _stream()),
+                                           M, D, drop_key & 0xFFFFFFFF, float(drop_p), _p(copy_colsum), _stream()),
               "va_layernorm_bwd_dropout")
         return dx_out
     check(lib.va_layernorm_bwd(_p(dy), int(dy.dtype == BF16), _p(x), _p(gamma), _p(mean), _p(rstd), _p(resid_grad),
