@@ -140,6 +140,17 @@ VA_DEVINL void store_rows(const f32x16_t (&acc)[HD / 32], float mul, bf16_t* out
         }
 }
 
+// Workgroup -> (head, 128-row block).  Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), so
+// taken literally the blocks of one head would land on all 8 XCDs and each XCD's L2 would fetch that head's K / V
+// (or Q / dO) for itself.  The remap hands every XCD a contiguous run of work ids instead: the blocks of a head run
+// on one XCD and share the head's operands in its L2.
+struct HeadBlock { int bh, blk; };
+VA_DEVINL HeadBlock head_block() {
+    const int nblk = gridDim.x;
+    const int v = xcd_remap(blockIdx.y * nblk + blockIdx.x, nblk * gridDim.y);
+    return {v / nblk, v % nblk};
+}
+
 // LDS ring depth of the forward kernel: three 16 KiB slots at head dim 64 (three workgroups per CU still
 // fit), two 32 KiB slots at head dim 128.
 constexpr int fwd_ring_slots(int hd) { return hd == 64 ? 3 : 2; }
@@ -179,8 +190,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const HeadBlock hb = head_block();
+    const int bh = hb.bh, b = bh / H, hh = bh % H;
+    const int q0 = hb.blk * 128 + wave * 32;
     const bf16_t* Qb = Q + (int64_t)b * N * ld + hh * HD;
     const bf16_t* Kb = K + (int64_t)b * N * ld + hh * HD;
     const bf16_t* Vb = V + (int64_t)b * N * ld + hh * HD;
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     int nt = (N + TILE_ROWS - 1) / TILE_ROWS;       // tiles the workgroup walks (uniform)
     if (MODE == 2) {
         klim = (qrow_c / tpt + 1) * tpt;
-        int q_last = blockIdx.x * 128 + 127;
+        int q_last = hb.blk * 128 + 127;
         q_last = q_last < N ? q_last : N - 1;
         nt = ((q_last / tpt + 1) * tpt + TILE_ROWS - 1) / TILE_ROWS;
     }
@@ -395,8 +407,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const HeadBlock hb = head_block();
+    const int bh = hb.bh, b = bh / H, hh = bh % H;
+    const int q0 = hb.blk * 128 + wave * 32;
     const bf16_t* Qb = Q + (int64_t)b * N * ld + hh * HD;
     const bf16_t* Kb = K + (int64_t)b * N * ld + hh * HD;
     const bf16_t* Vb = V + (int64_t)b * N * ld + hh * HD;
@@ -544,8 +557,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE] | 16 zero bytes
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, hh = bh % H;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const HeadBlock hb = head_block();
+    const int bh = hb.bh, b = bh / H, hh = bh % H;
+    const int k0 = hb.blk * 128 + wave * 32;
     const bf16_t* Qb = Q + (int64_t)b * N * ld + hh * HD;
     const bf16_t* Kb = K + (int64_t)b * N * ld + hh * HD;
     const bf16_t* Vb = V + (int64_t)b * N * ld + hh * HD;
