@@ -26,7 +26,7 @@ x = rnd((M, D)); x4 = rnd((M, 4 * D))
 for name, (Nn, K) in {"qkv": (3 * D, D), "out": (D, D), "fc1": (4 * D, D), "fc2": (D, 4 * D)}.items():
     w = rnd((Nn, K), scale=1 / math.sqrt(K)); a = x if K == D else x4
     out = torch.empty(M, Nn, dtype=BF16, device=dev)
-    for tile in (2256, 256):
+    for tile in (4256, 256):
         t = timeit(lambda: ops.gemm_nt(a, w, ops.EPI_BF16, out, tile=tile))
         print(f"gemm_nt {name} tile{tile}: {t*1e3:.3f} ms  {2*M*Nn*K/t/1e12:.1f} TF/s", flush=True)
     dw = torch.zeros(Nn, K, dtype=F32, device=dev)

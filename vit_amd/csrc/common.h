@@ -113,6 +113,19 @@ VA_DEVINL int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// Work id -> (m-tile, n-tile) of a GEMM.  Ids run over groups of 8 m-panels, m fastest inside a group: the ~32
+// workgroups an XCD runs at a time (consecutive ids after xcd_remap) then cover 8 activation panels x 4 weight
+// panels instead of 2 x 16, i.e. 12 distinct operand panels instead of 18 go through that XCD's L2 per round.
+VA_DEVINL void grouped_tile(int id, int tiles_m, int tiles_n, int& mt, int& nt) {
+    constexpr int G = 8;
+    const int per = G * tiles_n;
+    const int grp = id / per, within = id - grp * per;
+    const int left = tiles_m - grp * G;
+    const int gm = left < G ? left : G;
+    nt = within / gm;
+    mt = grp * G + within % gm;
+}
+
 // ---- dropout masks ------------------------------------------------------
 // Counter-based keep/drop decisions.  Elements 2*pair and 2*pair+1 share one 32-bit word
 //     h = mix(pair * DROP_WEYL + key),   mix(w): w ^= w >> 16; w *= DROP_MUL; w ^= w >> 15

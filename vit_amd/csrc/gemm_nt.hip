@@ -347,9 +347,10 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
 
     const int tiles_n = N / BN;
     const int tiles_m = (M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (id / tiles_n) * BM;
-    const int n0 = (id % tiles_n) * BN;
+    int mt_, nt_;
+    grouped_tile(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, mt_, nt_);
+    const int m0 = mt_ * BM;
+    const int n0 = nt_ * BN;
 
     // staging: 1024 chunks per operand per stage, 2 per thread: chunk q -> row q>>2, slot q&3
     const bf16_t* xsrc[2];
@@ -566,9 +567,10 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         __amdgpu_buffer_rsrc_t x, w;
     };
     auto set_tile = [&](int v, Tile& t) {
-        const int id = xcd_remap(v, tiles);
-        t.m0 = (id / tiles_n) * BM;
-        t.n0 = (id % tiles_n) * BN;
+        int mt, nt;
+        grouped_tile(xcd_remap(v, tiles), tiles_m, tiles_n, mt, nt);
+        t.m0 = mt * BM;
+        t.n0 = nt * BN;
         const int64_t xb = (int64_t)(M - t.m0) * ldx * 2, wb = (int64_t)(N - t.n0) * ldw * 2;
         t.x = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (size_t)t.m0 * ldx), (short)0,
                                                 (int)(xb < 0x7fffffff ? xb : 0x7fffffff), 0x00020000);
