@@ -113,11 +113,12 @@ VA_DEVINL int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-// Work id -> (m-tile, n-tile) of a GEMM.  Ids run over groups of 8 m-panels, m fastest inside a group: the ~32
-// workgroups an XCD runs at a time (consecutive ids after xcd_remap) then cover 8 activation panels x 4 weight
-// panels instead of 2 x 16, i.e. 12 distinct operand panels instead of 18 go through that XCD's L2 per round.
+// Work id -> (m-tile, n-tile) of a GEMM.  Ids run over groups of G m-panels, m fastest inside a group: the ~32
+// workgroups an XCD runs at a time (consecutive ids after xcd_remap) then cover G activation panels x 32/G weight
+// panels instead of 2 x 16: fewer distinct operand panels go through that XCD's L2 per round.  G = 4 measured best
+// on the whole training step (2, 3, 6, 8 within 1 %; 16 -- activation panels alone overflow the L2 -- 5 % worse).
 VA_DEVINL void grouped_tile(int id, int tiles_m, int tiles_n, int& mt, int& nt) {
-    constexpr int G = 8;
+    constexpr int G = 4;
     const int per = G * tiles_n;
     const int grp = id / per, within = id - grp * per;
     const int left = tiles_m - grp * G;
