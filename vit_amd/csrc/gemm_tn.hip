@@ -210,8 +210,10 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
     const int tiles_k = K / 256;
     const int tiles = (N / 256) * tiles_k;
     const int id = work % tiles;
-    const int n0 = (id / tiles_k) * 256;
-    const int k0 = (id % tiles_k) * 256;
+    int nt_, kt_;
+    grouped_tile(id, N / 256, tiles_k, nt_, kt_);     // compact blocks of tiles per XCD run, as in the NT kernels
+    const int n0 = nt_ * 256;
+    const int k0 = kt_ * 256;
     const int m_begin = (work / tiles) * m_per_slice;
     int m_end = m_begin + m_per_slice;
     m_end = m_end < M ? m_end : M;
@@ -318,7 +320,7 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
     };
     // the bias column sums are spread over the k-tile workgroups of an output row: each takes every
     // tiles_k-th stage, so no workgroup carries more than 1/tiles_k of the extra MFMAs
-    const int my_ktile = id % tiles_k;
+    const int my_ktile = kt_;
     auto bias_stage = [&](int stage_idx) { return DO_BIAS && (stage_idx % tiles_k) == my_ktile; };
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
