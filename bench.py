@@ -11,7 +11,8 @@ roofline: the dominant kernel is the 256x256-tile bf16 MFMA GEMM (plain bf16 epi
 bracketed with HIP events on the launch stream during the timed steps; achieved = algorithmic FLOPs
 (2*M*N*K per launch) / measured time, against the 2.5 PFLOP/s dense bf16 peak.
 cpu_baseline: the CPU oracle (a from-scratch port of the reference arithmetic, fp32) on this host's
-cores for ONE clip forward+backward of the same model -- rank 0, N = 1 only.
+cores for ONE clip forward+backward of the same model, same weights, same clip -- rank 0, N = 1 only; the
+device's output for that clip is compared with the oracle's (relative L2) in the same leg.
 """
 import argparse
 import json
@@ -69,18 +70,20 @@ class GemmProbe:
         return {"launches": len(self.records), "flops": fl, "seconds": ms * 1e-3}
 
 
-def cpu_baseline():
-    """One ViT-L clip forward+backward through the CPU oracle (fp32, all host threads torch uses)."""
+def cpu_baseline(enc, clip, y_gpu):
+    """One ViT-L clip forward+backward through the CPU oracle (fp32, all host threads torch uses) on the SAME weights
+    and the same clip the device model just ran: besides the timing, the relative L2 distance between the device's
+    output for that clip and the oracle's is reported."""
     from oracle import ref_cpu as R
-    torch.manual_seed(42)
-    P = {k: (torch.randn(s) * 0.02).requires_grad_(True) for k, s in R.encoder_param_shapes(DEPTH).items()}
-    video = torch.randn(1, 3, FRAMES, IMG, IMG, generator=torch.Generator().manual_seed(1234))
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in enc.state_dict().items() if "inv_freq" not in k}
     t0 = time.perf_counter()
-    y = R.encoder_forward(P, video, DEPTH, HEADS)
+    y = R.encoder_forward(P, clip, DEPTH, HEADS)
     (y ** 2).mean().backward()
     dt = time.perf_counter() - t0
+    err = ((y_gpu - y.detach()).norm() / y.detach().norm()).item()
     return {"value": 1.0 / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 clip (16x256x256, 2048 tokens) forward+backward through all {DEPTH} blocks, fp32, {dt:.1f} s"}
+            "sample": f"1 clip (16x256x256, 2048 tokens) forward+backward through all {DEPTH} blocks, fp32, {dt:.1f} s",
+            "device_vs_oracle_output_rel_l2": round(err, 6)}
 
 
 def main():
@@ -189,7 +192,10 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            enc.eval()                                   # the oracle's arithmetic is the eval-mode one
+            with torch.no_grad():
+                y_gpu = enc(video[:1].contiguous()).cpu()
+            out["cpu_baseline"] = cpu_baseline(enc, video[:1].cpu(), y_gpu)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -110,6 +110,15 @@ int va_layernorm_bwd_dropout(const void* dy, int dy_bf16, const float* x, const 
 int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, int64_t Tp, int64_t Hp, int64_t Wp,
                          int inverse, va_stream_t stream);
 
+/* The general form of the same rotation, for RoPEMultiheadAttention.forward called on its own with any cache and any
+ * token positions (swm:265-281, 300-303): cos_x / sin_x are the full-width f32 tables VideoRoPE3D.forward returns
+ * ([len_t, 256], [len_h, 384], [len_w, 384]; the two halves of a row need not be equal) and pos is an int32 [3, N]
+ * array of per-token (t, h, w) table rows, the same for every sequence of N tokens in the M rows.  The caller
+ * guarantees 0 <= pos < len.  transpose != 0 applies the transposed rotation (the backward). */
+int va_rope3d_qk_indexed(void* qkv, const float* cos_t, const float* sin_t, const float* cos_h, const float* sin_h,
+                         const float* cos_w, const float* sin_w, const int32_t* pos, int64_t M, int64_t N,
+                         int transpose, va_stream_t stream);
+
 /* ---- flash attention (swm:306-331: softmax(q k^T * hd^-0.5) v, no mask, eval-mode dropout) ---------
  * q,k,v: bf16, element (b, n, h, d) at ((b*N + n)*ld + h*hd + d) of the respective base pointer (so the
  * three thirds of one packed qkv buffer can be passed with ld = 3*D).  o likewise with ldo.
@@ -180,7 +189,8 @@ int va_multi_cast_f32_bf16(const va_cast_job* jobs, int64_t njobs, int64_t total
 int va_future_mask(const void* x, void* out, uint8_t* mask, int64_t B, int64_t N, int64_t D, int64_t elem_bytes,
                    int64_t first_masked_row, va_stream_t stream);
 /* Row gather out[b,j,:] = x[b, idx[b,j], :] and its inverse scatter (out pre-zeroed by the call).
- * No reference symbol: these serve JEPA-style context/target token selection. row_bytes % 16 == 0. */
+ * No reference symbol: these serve JEPA-style context/target token selection. row_bytes % 16 == 0.
+ * An index outside [0, N) touches no memory: the gather writes a zero row for it, the scatter skips it. */
 int va_token_gather(const void* x, const int32_t* idx, void* out, int64_t B, int64_t N_src, int64_t N_keep,
                     int64_t row_bytes, va_stream_t stream);
 int va_token_scatter(const void* src, const int32_t* idx, void* out, int64_t B, int64_t N_dst, int64_t N_keep,

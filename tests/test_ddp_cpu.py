@@ -100,3 +100,93 @@ def test_reducer_is_a_noop_for_one_rank(tmp_path):
         assert torch.equal(t, torch.ones(5)) and r.buckets_reduced == 0
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the whole stage-1 step (heads, gathered InfoNCE, clip, AdamW) under data parallelism
+# ---------------------------------------------------------------------------------------------------------------
+class _StandInModel(torch.nn.Module):
+    """CPU stand-in for the world model with the surface `stage1_step` uses: `encode_video` (clips independent,
+    as through the real encoder) and `encoder.tubelet_embed.num_temporal_patches`."""
+
+    class _Enc(torch.nn.Module):
+        def __init__(self, dim, tokens):
+            super().__init__()
+            self.proj = torch.nn.Linear(12, tokens * dim)
+            self.tubelet_embed = type("T", (), {"num_temporal_patches": 2})()
+            self.tokens, self.dim = tokens, dim
+            self._grad_reducer = None
+
+        def forward(self, video):
+            return torch.tanh(self.proj(video.flatten(1))).view(video.shape[0], self.tokens, self.dim)
+
+    def __init__(self, dim=32, tokens=4):
+        super().__init__()
+        self.encoder = self._Enc(dim, tokens)
+
+    def encode_video(self, video):
+        return self.encoder(video)
+
+
+def _stage1_setup(seed):
+    from vit_amd import train_step as ts
+    from oracle import ref_cpu as R
+    # the masking kernel needs a device; on CPU the oracle's restatement of the same function stands in (test only)
+    ts.StructuredTemporalMasking = type("M", (), {"future_masking": staticmethod(R.future_masking)})
+    torch.manual_seed(seed)
+    model = _StandInModel()
+    heads = ts.Stage1Heads(dim=32).eval()              # eval: the classifier's nn.Dropout(0.1) is the identity
+    return ts, model, heads
+
+
+def _stage1_batch(gb):
+    g = torch.Generator().manual_seed(7)
+    return {"video": torch.randn(gb, 3, 2, 2, generator=g), "video_augmented": torch.randn(gb, 3, 2, 2, generator=g),
+            "shuffled_video": torch.randn(gb, 3, 2, 2, generator=g), "order_label": torch.randint(0, 2, (gb,), generator=g)}
+
+
+def _stage1_worker(rank, world, port, tmpdir, gb):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vit_amd.ddp import broadcast_parameters
+        ts, model, heads = _stage1_setup(100 + rank)            # different on purpose: the broadcast makes them equal
+        broadcast_parameters(model)
+        broadcast_parameters(heads)
+        params = list(model.parameters()) + list(heads.parameters())
+        opt = torch.optim.SGD(params, lr=0.5)      # plain SGD: the step is proportional to the clip coefficient
+        reducer = BucketReducer()
+        full = _stage1_batch(gb)
+        b, e = shard_range(gb, rank, world)
+        shard = {k: v[b:e] for k, v in full.items()}
+        for _ in range(2):
+            loss, parts = ts.stage1_step(model, heads, opt, shard, max_norm=0.05, reducer=reducer)
+        torch.save({"params": [p.detach().clone() for p in params], "loss": loss, "parts": [float(v) for v in parts]},
+                   os.path.join(tmpdir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gb", [6, 5])       # 5 clips over 2 ranks: shards of 3 and 2
+def test_stage1_step_two_ranks_equal_one_rank(tmp_path, gb):
+    """After two steps of `stage1_step` (heads + gathered InfoNCE + a global-norm clip that actually clips + SGD, whose update, unlike Adam's,
+    scales with the clip coefficient)
+    both ranks hold the parameters one rank gets on the concatenated batch: head gradients are averaged, the clip
+    norm is the global one, unequal shards are weighted."""
+    world = 2
+    mp.spawn(_stage1_worker, args=(world, _free_port(), str(tmp_path), gb), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f"rank{r}.pt", weights_only=True) for r in range(world)]
+
+    ts, model, heads = _stage1_setup(100)                       # rank 0's initial weights = what was broadcast
+    params = list(model.parameters()) + list(heads.parameters())
+    opt = torch.optim.SGD(params, lr=0.5)
+    full = _stage1_batch(gb)
+    for _ in range(2):
+        loss, parts = ts.stage1_step(model, heads, opt, full, max_norm=0.05)
+    for a, b in zip(got[0]["params"], got[1]["params"]):
+        assert torch.equal(a, b), "replicas drifted apart"
+    for a, ref in zip(got[0]["params"], params):
+        torch.testing.assert_close(a, ref.detach(), rtol=2e-4, atol=2e-6)
+    # the logged contrastive term is the global one on every rank
+    assert got[0]["parts"][1] == pytest.approx(float(parts[1]), rel=1e-4)
+    assert got[1]["parts"][1] == pytest.approx(float(parts[1]), rel=1e-4)

@@ -120,3 +120,55 @@ def test_predictor_pieces_on_cpu():
     np.testing.assert_allclose(state.numpy(), S.numpy(), atol=1e-5)
     y, st = layer(torch.randn(B, L, 64))
     assert y.shape == (B, L, 64) and st.shape == (B, 2, 32, 32)
+
+
+def test_unchanged_import_resolves_to_the_drop_in(golden_dir):
+    """The reference's scripts do `from surgical_world_model import SurgicalActionConditionedWorldModel`
+    (stage1_surgvu_pretraining.py:26, stage1_vjepa2_finetuning.py:40) and `... import ..., VideoViTEncoder`
+    (load_vjepa2_pretrained.py:23).  A child interpreter with only `dropin/` in front of the path must resolve
+    those imports to this package and build an encoder with the reference's state-dict keys."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, json\n"
+        "from surgical_world_model import SurgicalActionConditionedWorldModel, VideoViTEncoder\n"
+        "import surgical_world_model as m\n"
+        "import torch\n"
+        "torch.manual_seed(0)\n"
+        "enc = VideoViTEncoder(img_size=32, num_frames=4, embed_dim=1024, depth=1, num_heads=16)\n"
+        "print(json.dumps({'file': m.__file__, 'cls': SurgicalActionConditionedWorldModel.__module__,\n"
+        "                  'keys': list(enc.state_dict().keys()), 'all': sorted(m.__all__)}))\n")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env["PYTHONPATH"] = os.path.join(ROOT, "dropin")
+    out = subprocess.run([sys.executable, "-c", code], cwd="/", env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    import json
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info["file"] == os.path.join(ROOT, "dropin", "surgical_world_model.py")
+    assert info["cls"] == "vit_amd.surgical_world_model"
+    g = np.load(os.path.join(golden_dir, "seed_canary.npz"), allow_pickle=False)
+    assert info["keys"] == [str(k) for k in g["keys"]]
+    for name in ("rotate_half", "apply_rotary_pos_emb", "TubeletEmbedding", "VideoRoPE3D", "RoPEMultiheadAttention",
+                 "GatedDeltaLayer", "VideoViTBlock", "VideoViTEncoder", "ActionStateEmbedding", "HybridPredictorBlock",
+                 "BlockCausalMask", "SpatialAttentionPooling", "AutoregressivePredictor", "DualSterilityClassifier",
+                 "SurgicalActionConditionedWorldModel"):
+        assert name in info["all"], name
+
+
+def test_rotary_helpers_match_their_definition():
+    x = torch.arange(8.0).view(1, 8)
+    assert torch.equal(M.rotate_half(x), torch.tensor([[-4.0, -5, -6, -7, 0, 1, 2, 3]]))
+    cos, sin = torch.full((1, 8), 0.5), torch.full((1, 8), 2.0)
+    assert torch.equal(M.apply_rotary_pos_emb(x, cos, sin), x * cos + M.rotate_half(x) * sin)
+    att = M.RoPEMultiheadAttention(1024, 16, rope_dims={"t_dim": 256, "h_dim": 384, "w_dim": 384})
+    grid = (2, 2, 2)
+    cache = M.VideoRoPE3D(1024)(*grid)
+    enc = M.VideoViTEncoder.__new__(M.VideoViTEncoder)
+    pos = M.VideoViTEncoder._create_token_positions(enc, *grid, device="cpu")
+    q = R.hashed_uniform("api.rope.q", (2, 8, 1024), 1.0)
+    torch.testing.assert_close(att.apply_rope_to_qk(q, cache, pos), R.rope_rotate(q, *grid), rtol=1e-6, atol=1e-6)
+    # stand-alone forwards refuse CPU tensors instead of computing somewhere else
+    for call in (lambda: att(q), lambda: M.TubeletEmbedding(32, 4)(torch.zeros(1, 3, 4, 32, 32)),
+                 lambda: M.VideoViTBlock(1024, 16)(q)):
+        with pytest.raises(_lib.VitAmdError):
+            call()

@@ -1,0 +1,192 @@
+"""GPU: the encoder's building blocks run on their own -- `TubeletEmbedding.forward`, `RoPEMultiheadAttention.forward`,
+`VideoViTBlock.forward` (surgical_world_model.py:92-109, 283-336, 705-714) -- against the reference's golden vectors
+(tests/golden/tubelet.npz, attention.npz) and the CPU oracle, forward and backward.
+
+Tolerance as for the encoder: relative L2 <= 2e-2 (bf16 operands, f32 accumulation).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 2e-2
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def swm():
+    assert torch.cuda.is_available()
+    from vit_amd import surgical_world_model as m
+    return m
+
+
+def _fill(module, prefix):
+    sd = R.fill_state_dict_({prefix + k: v for k, v in module.state_dict().items()})
+    module.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    return sd
+
+
+def test_tubelet_embedding_forward_matches_reference_and_backward_matches_oracle(swm, golden_dir):
+    g = np.load(os.path.join(golden_dir, "tubelet.npz"), allow_pickle=False)
+    te = swm.TubeletEmbedding(img_size=32, num_frames=4, tubelet_size=(2, 16, 16), in_channels=3, embed_dim=1024)
+    sd = _fill(te, "tubelet_embed.")
+    te = te.cuda()
+    video = torch.from_numpy(g["video"])
+    v = video.cuda().requires_grad_(True)
+    y = te(v)
+    ref = torch.from_numpy(g["out"])
+    assert y.shape == ref.shape and rel(y, ref) < REL_TOL
+    gy = R.hashed_uniform("mod.te.gy", tuple(ref.shape), 1.0)
+    (y * gy.cuda()).sum().backward()
+    w = sd["tubelet_embed.projection.weight"].clone().requires_grad_(True)
+    b = sd["tubelet_embed.projection.bias"].clone().requires_grad_(True)
+    v2 = video.clone().requires_grad_(True)
+    (R.tubelet_embed(v2, w, b) * gy).sum().backward()
+    assert rel(te.projection.weight.grad, w.grad) < REL_TOL
+    assert rel(te.projection.bias.grad, b.grad) < REL_TOL
+    assert rel(v.grad, v2.grad) < REL_TOL
+
+
+def _canonical(swm, grid, device):
+    cache = swm.VideoRoPE3D(1024)(*grid)
+    enc = swm.VideoViTEncoder.__new__(swm.VideoViTEncoder)
+    pos = swm.VideoViTEncoder._create_token_positions(enc, *grid, device=device)
+    return tuple(tuple(t.to(device) for t in pair) for pair in cache), pos
+
+
+@pytest.mark.parametrize("heads", [16, 8])
+def test_attention_forward_backward_match_reference_golden(swm, golden_dir, heads):
+    g = np.load(os.path.join(golden_dir, "attention.npz"), allow_pickle=False)
+    att = swm.RoPEMultiheadAttention(1024, heads, rope_dims={"t_dim": 256, "h_dim": 384, "w_dim": 384}).eval()
+    _fill(att, "blocks.0.attn.")
+    att = att.cuda()
+    cache, pos = _canonical(swm, (2, 2, 2), "cuda")
+    tag = f"h{heads}_nomask"
+    x = torch.from_numpy(g[f"x_{tag}"]).cuda().requires_grad_(True)
+    y = att(x, rope_cache=cache, token_positions=pos)
+    assert rel(y, torch.from_numpy(g[f"y_{tag}"])) < REL_TOL
+    (y * torch.from_numpy(g[f"gy_{tag}"]).cuda()).sum().backward()
+    assert rel(x.grad, torch.from_numpy(g[f"dx_{tag}"])) < REL_TOL
+    for nm, p in (("dwqkv", att.qkv_proj.weight), ("dwout", att.out_proj.weight)):
+        flat = p.grad.reshape(-1).double().cpu()
+        got, want = flat[torch.from_numpy(g[f"{nm}_{tag}_pos"])], torch.from_numpy(g[f"{nm}_{tag}_val"])
+        assert ((got - want).norm() / want.norm()).item() < 5e-2, nm       # 64 sampled entries
+        np.testing.assert_allclose(flat.abs().sum().item(), g[f"{nm}_{tag}_digest"][1], rtol=2e-2)
+
+    # the reference's masked case (upper-triangular mask = block-causal with one token per timestep): forward only
+    tag = f"h{heads}_mask"
+    xm = torch.from_numpy(g[f"x_{tag}"]).cuda()
+    mask = torch.triu(torch.ones(8, 8, dtype=torch.bool, device="cuda"), diagonal=1)
+    with torch.no_grad():
+        ym = att(xm, rope_cache=cache, token_positions=pos, attn_mask=mask)
+    assert rel(ym, torch.from_numpy(g[f"y_{tag}"])) < REL_TOL
+    from vit_amd._lib import VitAmdError
+    with pytest.raises(VitAmdError):            # no masked backward kernel: loud, not silently unmasked
+        att(xm.requires_grad_(True), rope_cache=cache, token_positions=pos, attn_mask=mask).sum().backward()
+    with pytest.raises(VitAmdError):            # arbitrary boolean masks have no kernel at all
+        att(xm, attn_mask=torch.rand(8, 8, device="cuda") < 0.3)
+
+
+def test_attention_without_rope_and_with_arbitrary_positions(swm):
+    """rope_cache=None skips the rotation (swm:301); a cache whose halves differ and positions in any order go through
+    the general rotation kernel: y_a = x_a cos_a - x_b sin_a, y_b = x_b cos_b + x_a sin_b per segment (swm:265-281)."""
+    heads, B, N = 16, 2, 24
+    att = swm.RoPEMultiheadAttention(1024, heads, rope_dims={"t_dim": 256, "h_dim": 384, "w_dim": 384}).eval()
+    sd = _fill(att, "blocks.0.attn.")
+    att = att.cuda()
+    x = R.hashed_uniform("mod.attn.x", (B, N, 1024), 1.0)
+    wq, wo = sd["blocks.0.attn.qkv_proj.weight"], sd["blocks.0.attn.out_proj.weight"]
+    y0 = att(x.cuda())
+    assert rel(y0, R.rope_attention(x, wq, wo, heads, None)) < REL_TOL
+
+    lens = (5, 7, 6)
+    cache = tuple((R.hashed_uniform(f"mod.cos{a}", (n, d), 1.0), R.hashed_uniform(f"mod.sin{a}", (n, d), 1.0))
+                  for a, (n, d) in enumerate(zip(lens, (256, 384, 384))))
+    gen = torch.Generator().manual_seed(3)
+    pos = {k: torch.randint(0, n, (N,), generator=gen) for k, n in zip(("t_idx", "h_idx", "w_idx"), lens)}
+
+    def rotate(t):                      # the reference formula, written out
+        out, c0 = [], 0
+        for (cos, sin), key, d in zip(cache, ("t_idx", "h_idx", "w_idx"), (256, 384, 384)):
+            seg = t[..., c0:c0 + d]
+            rot = torch.cat([-seg[..., d // 2:], seg[..., :d // 2]], dim=-1)
+            out.append(seg * cos[pos[key]] + rot * sin[pos[key]])
+            c0 += d
+        return torch.cat(out, dim=-1)
+
+    xr = x.clone().requires_grad_(True)
+    wq_r, wo_r = wq.clone().requires_grad_(True), wo.clone().requires_grad_(True)
+    qkv = xr @ wq_r.t()
+    q, k, v = rotate(qkv[..., :1024]), rotate(qkv[..., 1024:2048]), qkv[..., 2048:]
+    sp = lambda t: t.reshape(B, N, heads, 64).permute(0, 2, 1, 3)
+    p = ((sp(q) @ sp(k).transpose(-1, -2)) * 64 ** -0.5).softmax(dim=-1)
+    ref = (p @ sp(v)).permute(0, 2, 1, 3).reshape(B, N, 1024) @ wo_r.t()
+    gy = R.hashed_uniform("mod.attn.gy", (B, N, 1024), 1.0)
+    (ref * gy).sum().backward()
+
+    xg = x.cuda().requires_grad_(True)
+    y = att(xg, rope_cache=cache, token_positions=pos)
+    (y * gy.cuda()).sum().backward()
+    assert rel(y, ref) < REL_TOL
+    assert rel(xg.grad, xr.grad) < REL_TOL
+    assert rel(att.qkv_proj.weight.grad, wq_r.grad) < REL_TOL
+    assert rel(att.out_proj.weight.grad, wo_r.grad) < REL_TOL
+    with pytest.raises(IndexError):
+        att(xg, rope_cache=cache, token_positions={**pos, "t_idx": pos["t_idx"] + 5})
+
+
+@pytest.mark.parametrize("heads,grid", [(16, (2, 4, 4)), (8, (1, 3, 5))])
+def test_block_forward_backward_match_oracle(swm, heads, grid):
+    B, N = 2, grid[0] * grid[1] * grid[2]
+    blk = swm.VideoViTBlock(1024, heads, {"t_dim": 256, "h_dim": 384, "w_dim": 384}).eval()
+    sd = _fill(blk, "blocks.0.")
+    blk = blk.cuda()
+    cache, pos = _canonical(swm, grid, "cuda")
+    x = R.hashed_uniform("mod.blk.x", (B, N, 1024), 1.0)
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = R.vit_block(xr, P, "blocks.0.", heads, grid)
+    gy = R.hashed_uniform("mod.blk.gy", (B, N, 1024), 1.0)
+    (ref * gy).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = blk(xg, rope_cache=cache, token_positions=pos)
+    (y * gy.cuda()).sum().backward()
+    assert y.dtype == torch.float32 and rel(y, ref) < REL_TOL
+    assert rel(xg.grad, xr.grad) < REL_TOL
+    errs = {k: rel(p.grad, P["blocks.0." + k].grad) for k, p in blk.named_parameters()}
+    assert all(e < REL_TOL for e in errs.values()), errs
+
+
+def test_block_training_mode_dropout_matches_oracle_on_identical_masks(swm):
+    """model.train(): the three nn.Dropout(0.1) of the block are applied; the keys come from torch's CPU generator in
+    the order attention, after-GELU, after-fc2, so the oracle can rebuild the very same masks."""
+    heads, grid, B = 16, (2, 2, 4), 2
+    N = 16
+    blk = swm.VideoViTBlock(1024, heads, {"t_dim": 256, "h_dim": 384, "w_dim": 384}).train()
+    sd = _fill(blk, "blocks.0.")
+    blk = blk.cuda()
+    cache, pos = _canonical(swm, grid, "cuda")
+    x = R.hashed_uniform("mod.blk.xd", (B, N, 1024), 1.0)
+    torch.manual_seed(11)
+    keys = tuple(int(torch.randint(0, 2 ** 32, (1,), dtype=torch.int64)) for _ in range(3))
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = R.vit_block(x, P, "blocks.0.", heads, grid, drop=((0.1, 0.1, 0.1), keys))
+    gy = R.hashed_uniform("mod.blk.gyd", (B, N, 1024), 1.0)
+    (ref * gy).sum().backward()
+    torch.manual_seed(11)
+    y = blk(x.cuda(), rope_cache=cache, token_positions=pos)
+    (y * gy.cuda()).sum().backward()
+    assert rel(y, ref) < REL_TOL
+    errs = {k: rel(p.grad, P["blocks.0." + k].grad) for k, p in blk.named_parameters()}
+    assert all(e < REL_TOL for e in errs.values()), errs
+    blk.eval()
+    with torch.no_grad():
+        assert rel(blk(x.cuda(), rope_cache=cache, token_positions=pos), R.vit_block(x, sd, "blocks.0.", heads, grid)) < REL_TOL

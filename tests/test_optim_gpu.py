@@ -55,3 +55,73 @@ def test_fused_adamw_drives_the_encoder_step():
     with torch.no_grad():
         after = enc(video)
     assert torch.isfinite(after).all() and not torch.equal(before, after)
+
+
+def test_two_param_groups_scheduler_and_state_dict_interchange(tmp_path):
+    """The fine-tuning recipe (stage1_vjepa2_finetuning.py:216-239): two groups, the encoder at 0.1x the learning
+    rate, a LambdaLR on top; one global clip norm over both groups.  Then checkpoint interchange: the state dict
+    has torch.optim.AdamW's layout, loads into a fresh FusedAdamW and into torch.optim.AdamW (and back), and the
+    resumed optimizers keep producing the same parameters."""
+    from vit_amd.optim import FusedAdamW
+
+    def groups(ps, lr):
+        return [{"params": ps[:3], "lr": lr * 0.1}, {"params": ps[3:], "lr": lr}]
+
+    ref_p = [torch.nn.Parameter(t.clone().cuda()) for t in make_params(0)]
+    my_p = [torch.nn.Parameter(t.clone().cuda()) for t in make_params(0)]
+    ref = torch.optim.AdamW(groups(ref_p, 2e-3), weight_decay=0.05)
+    mine = FusedAdamW(groups(my_p, 2e-3), weight_decay=0.05, max_grad_norm=1.0)
+    assert isinstance(mine, torch.optim.Optimizer) and mine.param_groups is mine.param_groups
+    sched = lambda e: (e + 1) / 2 if e < 2 else 0.5       # warm-up then a lower plateau
+    s_ref = torch.optim.lr_scheduler.LambdaLR(ref, sched)
+    s_mine = torch.optim.lr_scheduler.LambdaLR(mine, sched)
+
+    def one_step(opt_ref, opt_mine, pr, pm, seed):
+        grads = make_params(seed)
+        for a, b, g in zip(pr, pm, grads):
+            a.grad, b.grad = (g * 2).cuda(), (g * 2).cuda()
+        torch.nn.utils.clip_grad_norm_(pr, max_norm=1.0)
+        opt_ref.step()
+        opt_mine.step()
+
+    for step in range(3):
+        one_step(ref, mine, ref_p, my_p, 200 + step)
+        s_ref.step()
+        s_mine.step()
+        assert [g["lr"] for g in mine.param_groups] == pytest.approx([g["lr"] for g in ref.param_groups])
+        for a, b in zip(ref_p, my_p):
+            assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (step, a.shape)
+
+    # ---- save / load: same keys as torch.optim.AdamW's state, through torch.save like s1:504
+    sd = mine.state_dict()
+    sd_ref = ref.state_dict()
+    assert set(sd["state"].keys()) == set(sd_ref["state"].keys())
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd["state"][0]["step"]) == float(sd_ref["state"][0]["step"]) == 3.0
+    torch.save({"optimizer": sd}, tmp_path / "ck.pth")
+    loaded = torch.load(tmp_path / "ck.pth", weights_only=True)["optimizer"]
+
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in my_p]
+    resumed = FusedAdamW(groups(p2, 1.0), weight_decay=0.0, max_grad_norm=1.0)
+    resumed.load_state_dict(loaded)                                 # hyper-parameters come from the file
+    p3 = [torch.nn.Parameter(p.detach().clone()) for p in my_p]
+    torch_resumed = torch.optim.AdamW(groups(p3, 1.0))
+    torch_resumed.load_state_dict(loaded)                           # FusedAdamW file -> torch.optim.AdamW
+    p4 = [torch.nn.Parameter(p.detach().clone()) for p in my_p]
+    from_torch = FusedAdamW(groups(p4, 1.0), max_grad_norm=1.0)
+    from_torch.load_state_dict(ref.state_dict())                    # torch.optim.AdamW file -> FusedAdamW
+
+    grads = make_params(999)
+    for plist in (my_p, p2, p3, p4, ref_p):
+        for p, g in zip(plist, grads):
+            p.grad = (g * 2).cuda()
+    torch.nn.utils.clip_grad_norm_(p3, max_norm=1.0)
+    torch.nn.utils.clip_grad_norm_(ref_p, max_norm=1.0)
+    for o in (mine, resumed, torch_resumed, from_torch, ref):
+        o.step()
+    for a, b, c, d, e in zip(my_p, p2, p3, p4, ref_p):
+        assert torch.equal(a, b)                                    # resumed == never stopped, bit for bit
+        assert torch.allclose(a, c, rtol=2e-6, atol=2e-7)
+        assert torch.allclose(a, d, rtol=2e-6, atol=2e-7)
+        assert torch.allclose(a, e, rtol=2e-6, atol=2e-7)
+    assert float(resumed.state[p2[0]]["step"]) == 4.0

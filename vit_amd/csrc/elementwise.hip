@@ -231,6 +231,54 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
     *(u32x4_t*)(base + col_a + half) = pack8(ob);
 }
 
+// The same rotation in its general form (RoPEMultiheadAttention.apply_rope_to_qk, swm:265-281, called with an
+// arbitrary cache and arbitrary token positions): full-width cos / sin tables per segment ([len, 256], [len, 384],
+// [len, 384] f32, the layout VideoRoPE3D.forward returns) and explicit per-token coordinates pos[3][N] (t, h, w).
+// The two halves of a table row are NOT assumed equal:  y_a = x_a*cos_a - x_b*sin_a,  y_b = x_b*cos_b + x_a*sin_b;
+// transpose != 0 applies the transposed map (the gradient):  dx_a = dy_a*cos_a + dy_b*sin_b,  dx_b = dy_b*cos_b - dy_a*sin_a.
+// Lane mapping as rope_kernel.
+__global__ __launch_bounds__(256) void rope_indexed_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                           const float* __restrict__ sin_t, const float* __restrict__ cos_h,
+                                                           const float* __restrict__ sin_h, const float* __restrict__ cos_w,
+                                                           const float* __restrict__ sin_w, const int32_t* __restrict__ pos,
+                                                           int64_t M, int N, int transpose) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 2 + (wave >> 1);
+    if (row >= M) return;
+    const int which = wave & 1;   // 0 = Q, 1 = K
+    const int n = (int)(row % N);
+    const int pi = lane * 8;
+    int col_a, half;
+    const float *ct, *st;
+    if (pi < 128) { col_a = pi; half = 128; ct = cos_t + (int64_t)pos[n] * 256 + pi; st = sin_t + (int64_t)pos[n] * 256 + pi; }
+    else if (pi < 320) { col_a = 256 + (pi - 128); half = 192; ct = cos_h + (int64_t)pos[N + n] * 384 + (pi - 128); st = sin_h + (int64_t)pos[N + n] * 384 + (pi - 128); }
+    else { col_a = 640 + (pi - 320); half = 192; ct = cos_w + (int64_t)pos[2 * N + n] * 384 + (pi - 320); st = sin_w + (int64_t)pos[2 * N + n] * 384 + (pi - 320); }
+    bf16_t* base = qkv + row * 3072 + which * 1024;
+    float a[8], b[8], ca[8], cb[8], sa[8], sb[8];
+    unpack8(*(const u32x4_t*)(base + col_a), a);
+    unpack8(*(const u32x4_t*)(base + col_a + half), b);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        *(f32x4_t*)(ca + 4 * q) = *(const f32x4_t*)(ct + 4 * q);
+        *(f32x4_t*)(cb + 4 * q) = *(const f32x4_t*)(ct + half + 4 * q);
+        *(f32x4_t*)(sa + 4 * q) = *(const f32x4_t*)(st + 4 * q);
+        *(f32x4_t*)(sb + 4 * q) = *(const f32x4_t*)(st + half + 4 * q);
+    }
+    float oa[8], ob[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (transpose) {
+            oa[j] = a[j] * ca[j] + b[j] * sb[j];
+            ob[j] = b[j] * cb[j] - a[j] * sa[j];
+        } else {
+            oa[j] = a[j] * ca[j] - b[j] * sa[j];
+            ob[j] = b[j] * cb[j] + a[j] * sb[j];
+        }
+    }
+    *(u32x4_t*)(base + col_a) = pack8(oa);
+    *(u32x4_t*)(base + col_a + half) = pack8(ob);
+}
+
 // ------------------------------------------------------------------------------------------------
 // tubelet gather: one thread per 8 consecutive pixels of a patch row.
 // ------------------------------------------------------------------------------------------------
@@ -395,7 +443,12 @@ __global__ __launch_bounds__(256) void token_move_kernel(const u32x4_t* __restri
     const int64_t r = gid / chunks_per_row;           // row in the compact (B, n_keep) space
     const int c = (int)(gid % chunks_per_row);
     const int64_t b = r / n_keep;
-    const int64_t full_row = b * n_full + idx[r];
+    const int32_t j = idx[r];
+    if ((uint32_t)j >= (uint32_t)n_full) {            // index outside [0, n_full): never touch memory outside the row range
+        if (!SCATTER) dst[gid] = (u32x4_t){0u, 0u, 0u, 0u};
+        return;
+    }
+    const int64_t full_row = b * n_full + j;
     if (SCATTER) dst[full_row * chunks_per_row + c] = src[gid];
     else dst[gid] = src[full_row * chunks_per_row + c];
 }
@@ -619,6 +672,20 @@ extern "C" int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, i
     hipLaunchKernelGGL(rope_kernel, dim3(blocks_for(M, 2)), dim3(256), 0, stream, (bf16_t*)qkv, tables, M, (int)Tp,
                        (int)Hp, (int)Wp, inverse ? -1.0f : 1.0f);
     VA_CHECK_LAUNCH("va_rope3d_qk_inplace");
+    return VA_OK;
+}
+
+extern "C" int va_rope3d_qk_indexed(void* qkv, const float* cos_t, const float* sin_t, const float* cos_h,
+                                    const float* sin_h, const float* cos_w, const float* sin_w, const int32_t* pos,
+                                    int64_t M, int64_t N, int transpose, hipStream_t stream) {
+    VA_CHECK_ARG(qkv && cos_t && sin_t && cos_h && sin_h && cos_w && sin_w && pos, "va_rope3d_qk_indexed: null operand");
+    VA_CHECK_ARG(M > 0 && N > 0 && N < (1ll << 30) && M % N == 0, "va_rope3d_qk_indexed: M=%lld is not a whole number of sequences of %lld tokens",
+                 (long long)M, (long long)N);
+    VA_CHECK_ARG(((uintptr_t)qkv | (uintptr_t)cos_t | (uintptr_t)sin_t | (uintptr_t)cos_h | (uintptr_t)sin_h | (uintptr_t)cos_w |
+                  (uintptr_t)sin_w) % 16 == 0 && (uintptr_t)pos % 4 == 0, "va_rope3d_qk_indexed: misaligned operand");
+    hipLaunchKernelGGL(rope_indexed_kernel, dim3(blocks_for(M, 2)), dim3(256), 0, stream, (bf16_t*)qkv, cos_t, sin_t, cos_h,
+                       sin_h, cos_w, sin_w, pos, M, (int)N, transpose);
+    VA_CHECK_LAUNCH("va_rope3d_qk_indexed");
     return VA_OK;
 }
 

@@ -211,6 +211,28 @@ def rope3d_qk_(qkv: torch.Tensor, tables: torch.Tensor, grid: Tuple[int, int, in
     return qkv
 
 
+def rope3d_qk_indexed_(qkv: torch.Tensor, cache, pos: torch.Tensor, n_tokens: int, transpose: bool = False):
+    """General rotation of the Q and K thirds of a packed [M, 3072] bf16 buffer (swm:265-281): `cache` =
+    ((cos_t, sin_t), (cos_h, sin_h), (cos_w, sin_w)) full-width f32 device tables as VideoRoPE3D.forward returns
+    them, `pos` int32 [3, n_tokens] table rows of every token (validated by the caller)."""
+    _need(qkv, BF16, "qkv"); _need(pos, torch.int32, "pos")
+    M, W3 = qkv.shape
+    if W3 != 3072 or not qkv.is_contiguous() or M % n_tokens:
+        raise ValueError("rope3d_qk_indexed_: qkv must be a contiguous [M, 3072] buffer of whole sequences")
+    if tuple(pos.shape) != (3, n_tokens) or not pos.is_contiguous():
+        raise ValueError("rope3d_qk_indexed_: pos must be a contiguous int32 [3, N] tensor")
+    flat = []
+    for (c, s_), width in zip(cache, (256, 384, 384)):
+        for t in (c, s_):
+            _need(t, F32, "rope table")
+            if t.dim() != 2 or t.shape[1] != width or not t.is_contiguous():
+                raise ValueError(f"rope3d_qk_indexed_: tables must be contiguous [len, {width}] f32")
+            flat.append(t)
+    check(_lib.load().va_rope3d_qk_indexed(_p(qkv), *(_p(t) for t in flat), _p(pos), M, n_tokens, int(transpose),
+                                           _stream()), "va_rope3d_qk_indexed")
+    return qkv
+
+
 # ------------------------------------------------------------------ attention
 def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2: torch.Tensor,
              tokens_per_timestep: int = 0, drop_key: int = 0, drop_p: float = 0.0):

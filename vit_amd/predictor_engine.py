@@ -20,9 +20,13 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 
 def block_supported(blk, x: torch.Tensor) -> bool:
+    """The LayerNorm kernel is 1024 wide, so both the block width and the memory layer's inner width must be 1024;
+    any other predictor size takes the torch formulation."""
     D = x.shape[-1]
     H = blk.spatial_attn.num_heads
-    return (D % 128 == 0 and D // H in (64, 128) and blk.spatial_attn.in_proj_bias is not None
+    if blk.use_deltanet and blk.temporal_layer.num_heads * blk.temporal_layer.head_dim != 1024:
+        return False
+    return (D == 1024 and D // H in (64, 128) and blk.spatial_attn.in_proj_bias is not None
             and blk.spatial_attn._qkv_same_embed_dim)
 
 

@@ -5,9 +5,10 @@ Same class names, constructor keywords, attributes, parameter names/shapes and c
 `VideoViTEncoder.forward` -- the path the training scripts spend their time in -- runs the hand-written
 HIP kernels of libvit_amd.so through `vit_amd.encoder_engine` instead of eager torch ops.
 
-What is NOT accelerated yet: the action-conditioned predictor (everything `forward()` does after the
-encoder) runs as ordinary torch ops on the device.  The encoder has no CPU path: calling it on CPU
-tensors raises.
+The encoder's building blocks (`TubeletEmbedding`, `RoPEMultiheadAttention`, `VideoViTBlock`) also run on
+their own, forward and backward, through the same kernels (`vit_amd.module_ops`).  The action-conditioned
+predictor runs its inference path (no autograd graph) on the kernels of `vit_amd.predictor_engine`; with autograd
+it uses a torch formulation of the same arithmetic.  Nothing on the encoder side has a CPU path: CPU tensors raise.
 
 Reference citations: swm = surgical_world_model.py of HananKibria/VIT.
 """
@@ -20,9 +21,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops, predictor_engine
+from . import module_ops, ops, predictor_engine
 from ._lib import VitAmdError
 from .encoder_engine import DropPlan, EncoderConfig, EncoderEngine, WeightCache, encoder_param_names
+
+__all__ = ["rotate_half", "apply_rotary_pos_emb", "TubeletEmbedding", "VideoRoPE3D", "RoPEMultiheadAttention",
+           "GatedDeltaLayer", "VideoViTBlock", "VideoViTEncoder", "ActionStateEmbedding", "HybridPredictorBlock",
+           "BlockCausalMask", "SpatialAttentionPooling", "AutoregressivePredictor", "DualSterilityClassifier",
+           "SurgicalActionConditionedWorldModel"]
 
 _ROPE_SPLIT = {"t_dim": 256, "h_dim": 384, "w_dim": 384}          # swm:731-735
 
@@ -31,23 +37,43 @@ def _inv_freq(d: int, base: float = 10000.0) -> torch.Tensor:
     return base ** (-torch.arange(0, d, 2).float() / d)           # swm:184-186
 
 
-def _rotate(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
-    """x*cos + (-x2 | x1)*sin with x = (x1 | x2) split in halves (swm:33-51)."""
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    """(x1 | x2) -> (-x2 | x1) (swm:33-36)."""
     half = x.shape[-1] // 2
-    return x * cos + torch.cat((-x[..., half:], x[..., :half]), dim=-1) * sin
+    return torch.cat((-x[..., half:], x[..., :half]), dim=-1)
 
 
-def _only_via_encoder(name: str):
-    raise NotImplementedError(
-        f"{name}.forward is not a standalone entry point in vit_amd: the block runs inside the fused "
-        "encoder schedule; call VideoViTEncoder / SurgicalActionConditionedWorldModel.encode_video")
+def apply_rotary_pos_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """x*cos + rotate_half(x)*sin (swm:39-51)."""
+    return x * cos + rotate_half(x) * sin
+
+
+_rotate = apply_rotary_pos_emb
+
+
+def _need_device(x: torch.Tensor, who: str) -> None:
+    if not x.is_cuda:
+        raise VitAmdError(f"{who} needs a HIP device tensor: vit_amd has no CPU fallback")
+
+
+def _draw_key() -> int:
+    """A dropout key from torch's default CPU generator (torch.manual_seed makes training runs repeatable)."""
+    return int(torch.randint(0, 2 ** 32, (1,), dtype=torch.int64))
+
+
+def _own_cache(module: nn.Module) -> WeightCache:
+    """bf16 operand copies of a stand-alone module's weights (refreshed when a parameter's version changes)."""
+    c = module.__dict__.get("_operand_cache")
+    if c is None:
+        c = module.__dict__["_operand_cache"] = WeightCache()
+    return c
 
 
 # =====================================================================================================
 # encoder: parameter containers + engine dispatch
 # =====================================================================================================
 class TubeletEmbedding(nn.Module):
-    """Holds the Conv3d patch projection (swm:58-109); the projection itself runs as gather + MFMA GEMM."""
+    """The Conv3d patch projection (swm:58-109), computed as patch gather + MFMA GEMM."""
 
     def __init__(self, img_size=224, num_frames=16, tubelet_size=(2, 16, 16), in_channels=3, embed_dim=1024):
         super().__init__()
@@ -60,7 +86,13 @@ class TubeletEmbedding(nn.Module):
         self.num_patches = self.num_temporal_patches * self.num_spatial_patches_h * self.num_spatial_patches_w
 
     def forward(self, video):
-        _only_via_encoder("TubeletEmbedding")
+        """(B,C,T,H,W) -> (B, T'H'W', D), T' slowest (swm:92-109): patch gather + MFMA GEMM (+bias)."""
+        _need_device(video, "TubeletEmbedding.forward")
+        w = self.projection.weight
+        if w.shape[1] != video.shape[1]:
+            raise ValueError(f"expected {w.shape[1]} channels, got {video.shape[1]}")
+        return module_ops.TubeletEmbedFn.apply(video, w, self.projection.bias, tuple(self.tubelet_size),
+                                               _own_cache(self), "pe")
 
     def inflate_weights_from_2d(self, pretrained_2d_weights: torch.Tensor):
         """Centre-frame inflation of a (out,in,h,w) filter bank into the 3-D projection (swm:111-151)."""
@@ -102,7 +134,8 @@ class VideoRoPE3D(nn.Module):
 
 
 class RoPEMultiheadAttention(nn.Module):
-    """Parameter container for the bias-free QKV / output projections (swm:225-263)."""
+    """Multi-head attention with the 3-D rotation applied to the full-width Q and K before the head split
+    (swm:225-336)."""
 
     def __init__(self, embed_dim, num_heads, rope_dims=None, dropout=0.1):
         super().__init__()
@@ -120,12 +153,69 @@ class RoPEMultiheadAttention(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim, bias=False)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, x, rope_cache=None, token_positions=None, attn_mask=None):
-        _only_via_encoder("RoPEMultiheadAttention")
+    def apply_rope_to_qk(self, qk, rope_cache, token_pos):
+        """Per column segment x*cos[idx] + rotate_half(x)*sin[idx] (swm:265-281), as torch ops (a helper for callers;
+        `forward` runs the rotation kernel)."""
+        if rope_cache is None or token_pos is None:
+            return qk
+        out, c0 = [], 0
+        for (cos, sin), key, d in zip(rope_cache, ("t_idx", "h_idx", "w_idx"),
+                                      (self.rope_dims["t_dim"], self.rope_dims["h_dim"], self.rope_dims["w_dim"])):
+            out.append(apply_rotary_pos_emb(qk[..., c0:c0 + d], cos[token_pos[key]], sin[token_pos[key]]))
+            c0 += d
+        return torch.cat(out, dim=-1)
+
+    def _rope_operands(self, rope_cache, token_positions, n_tokens: int, device):
+        """Device tables + int32 [3, N] positions for the rotation kernel, validated on the host (swm:265-281)."""
+        if rope_cache is None or token_positions is None:
+            return None
+        rd = self.rope_dims
+        if (rd["t_dim"], rd["h_dim"], rd["w_dim"]) != (256, 384, 384):
+            raise VitAmdError("the rotation kernel is built for the 256/384/384 split of a 1024-wide model "
+                              "(the only split the reference encoder constructs, swm:731-735)")
+        tables = tuple(tuple(t.detach().to(device=device, dtype=torch.float32).contiguous() for t in pair)
+                       for pair in rope_cache)
+        pos = torch.stack([token_positions[k].to(device) for k in ("t_idx", "h_idx", "w_idx")]).to(torch.int32).contiguous()
+        if tuple(pos.shape) != (3, n_tokens):
+            raise ValueError(f"token positions must have {n_tokens} entries per axis, got {tuple(pos.shape)}")
+        lens = torch.tensor([[tables[a][0].shape[0]] for a in range(3)], device=device)
+        if bool(((pos < 0) | (pos >= lens)).any()):
+            raise IndexError("token position outside the rotary table")
+        return tables, pos
+
+    @staticmethod
+    def _mask_period(attn_mask, L: int) -> int:
+        """0 for no mask, tokens-per-timestep for a block-causal mask (BlockCausalMask.create_mask); any other
+        boolean mask has no kernel."""
+        if attn_mask is None:
+            return 0
+        tpt = getattr(attn_mask, "tokens_per_timestep", None)
+        if tpt is None and attn_mask.dim() == 2 and tuple(attn_mask.shape) == (L, L) and attn_mask.dtype == torch.bool:
+            cand = int((~attn_mask[0]).sum())
+            if cand > 0 and L % cand == 0 and torch.equal(attn_mask, BlockCausalMask.create_mask(L, cand, attn_mask.device)):
+                tpt = cand
+        if not tpt or L % tpt:
+            raise VitAmdError("only block-causal boolean masks (every token sees its own and earlier timesteps) have an "
+                              "attention kernel; the encoder itself never passes a mask (swm:813)")
+        return int(tpt)
+
+    def forward(self, x, rope_cache=None, token_positions=None, attn_mask=None, _resid=None):
+        """swm:283-336 on the kernels: QKV GEMM, rotation of the full-width Q and K, flash attention, output GEMM.
+        `attn_mask` (True = masked) may be None or a block-causal mask; the latter is forward-only."""
+        _need_device(x, "RoPEMultiheadAttention.forward")
+        B, N, C = x.shape
+        if C != self.embed_dim or self.head_dim not in (64, 128) or C % 128:
+            raise VitAmdError(f"no attention kernel for embed_dim {C} with head_dim {self.head_dim} (64 or 128 needed)")
+        p = self.dropout.p if self.dropout.training else 0.0
+        spec = module_ops.AttnSpec(heads=self.num_heads, cache=_own_cache(self), key="",
+                                   rope=self._rope_operands(rope_cache, token_positions, N, x.device),
+                                   tokens_per_timestep=self._mask_period(attn_mask, N),
+                                   drop_key=_draw_key() if p > 0 else 0, drop_p=p)
+        return module_ops.RopeAttentionFn.apply(x, self.qkv_proj.weight, self.out_proj.weight, _resid, spec)
 
 
 class VideoViTBlock(nn.Module):
-    """Pre-LN attention + MLP block parameters (swm:681-703)."""
+    """Pre-LN attention + MLP block (swm:681-714)."""
 
     def __init__(self, embed_dim, num_heads, rope_dims=None, mlp_ratio=4.0, dropout=0.1):
         super().__init__()
@@ -137,7 +227,18 @@ class VideoViTBlock(nn.Module):
                                  nn.Linear(hidden, embed_dim), nn.Dropout(dropout))
 
     def forward(self, x, rope_cache=None, token_positions=None, attn_mask=None):
-        _only_via_encoder("VideoViTBlock")
+        """x + attn(LN1(x)), then x + mlp(LN2(x)) (swm:705-714); the residual adds ride in the GEMM epilogues."""
+        _need_device(x, "VideoViTBlock.forward")
+        if x.shape[-1] != 1024:
+            raise VitAmdError("the LayerNorm kernel is built for width 1024 (the only width the reference encoder admits)")
+        h = module_ops.LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, True)
+        x = self.attn(h, rope_cache=rope_cache, token_positions=token_positions, attn_mask=attn_mask, _resid=x)
+        h = module_ops.LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, True)
+        fc1, d1, fc2, d2 = self.mlp[0], self.mlp[2], self.mlp[3], self.mlp[4]
+        p1, p2 = (d1.p if d1.training else 0.0), (d2.p if d2.training else 0.0)
+        spec = module_ops.MlpSpec(cache=_own_cache(self), key="", drop1=(_draw_key() if p1 > 0 else 0, p1),
+                                  drop2=(_draw_key() if p2 > 0 else 0, p2))
+        return module_ops.MlpFn.apply(h, fc1.weight, fc1.bias, fc2.weight, fc2.bias, x, spec)
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -242,8 +343,16 @@ class VideoViTEncoder(nn.Module):
 # projections and the small heads are library GEMMs through torch.  With autograd the torch formulation of
 # the same arithmetic is used (the predictor is not trained by the stage-1 scripts).
 # =====================================================================================================
-def _hip_inference(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad)
+def _hip_inference(x: torch.Tensor, module: Optional[nn.Module] = None) -> bool:
+    """True when the inference kernels may run: device f32 input and no autograd graph to build -- neither through
+    the input nor (grad mode on) through a trainable parameter of `module`, whose gradient would otherwise be lost."""
+    if not (x.is_cuda and x.dtype == torch.float32):
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    if x.requires_grad:
+        return False
+    return module is None or not any(p.requires_grad for p in module.parameters())
 
 
 class GatedDeltaLayer(nn.Module):
@@ -291,7 +400,7 @@ class GatedDeltaLayer(nn.Module):
         B, L, _ = x.shape
         H, Dh = self.num_heads, self.head_dim
         alpha, beta = torch.sigmoid(self.a_proj(x)), torch.sigmoid(self.b_proj(x))
-        if _hip_inference(x) and Dh in (64, 128):
+        if _hip_inference(x, self) and Dh in (64, 128):
             q = ops.dwconv1d_causal_silu(self.q_proj(x), self.q_conv1d.weight, self.q_conv1d.bias, True)
             k = ops.dwconv1d_causal_silu(self.k_proj(x), self.k_conv1d.weight, self.k_conv1d.bias, True)
             v = ops.dwconv1d_causal_silu(self.v_proj(x), self.v_conv1d.weight, self.v_conv1d.bias, False)
@@ -371,7 +480,7 @@ class HybridPredictorBlock(nn.Module):
         H = a.num_heads
         qkv = F.linear(h, a.in_proj_weight, a.in_proj_bias)
         tpt = 0 if attn_mask is None else getattr(attn_mask, "tokens_per_timestep", -1)
-        if _hip_inference(h) and D // H in (64, 128) and tpt >= 0 and (tpt == 0 or L % tpt == 0):
+        if _hip_inference(h, self) and D // H in (64, 128) and tpt >= 0 and (tpt == 0 or L % tpt == 0):
             # packed [q | k | v] rows are exactly the attention kernel's layout; the mask is its block-causal mode
             o = torch.empty(B * L, D, dtype=torch.bfloat16, device=h.device)
             lse = torch.empty(B * H, L, dtype=torch.float32, device=h.device)
@@ -384,7 +493,7 @@ class HybridPredictorBlock(nn.Module):
 
     def forward(self, x, attn_mask=None, state=None):
         tpt = 0 if attn_mask is None else getattr(attn_mask, "tokens_per_timestep", -1)
-        if (_hip_inference(x) and tpt >= 0 and (tpt == 0 or x.shape[1] % tpt == 0)
+        if (_hip_inference(x, self) and tpt >= 0 and (tpt == 0 or x.shape[1] % tpt == 0)
                 and predictor_engine.block_supported(self, x)):
             if getattr(self, "_operand_cache", None) is None:
                 self._operand_cache = WeightCache()

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .ddp import all_gather_with_grad
+from .ddp import all_gather_with_grad, shard_weight
 from .masking import StructuredTemporalMasking
 
 
@@ -34,12 +34,46 @@ class Stage1Heads(nn.Module):
                              if use_mask_aux else None)
 
 
+def stage1_head_losses(heads: Stage1Heads, f_shuf, f_orig, f_aug, tokens, num_temporal_patches: int, order_label,
+                       lambda_mask: float = 0.1, temperature: float = 0.07,
+                       group: Optional[dist.ProcessGroup] = None):
+    """The step's loss arithmetic on pooled encoder features (s1:426-465): f_* are (B, D) mean-pooled features of
+    the shuffled / original / augmented views, `tokens` the (B, N, D) no-grad pass (None without the denoise head).
+
+    Returns (objective, (l_t, l_c, l_m)).  In a world of one the objective is l_t + l_c + lambda*l_m.  With several
+    ranks the InfoNCE negatives span the global batch (projections are all-gathered), and the objective is scaled
+    so that the rank-AVERAGED gradient equals the one-rank gradient on the concatenated batch: the gathered term
+    -- identical on every rank -- times world, the per-rank means times (B_local / B_global) * world."""
+    l_t = F.cross_entropy(heads.temporal_classifier(f_shuf), order_label)
+    z1 = F.normalize(heads.contrastive_proj(f_orig), dim=1)
+    z2 = F.normalize(heads.contrastive_proj(f_aug), dim=1)
+    world, b_local = 1, z1.shape[0]
+    if group is not None or (dist.is_initialized() and dist.get_world_size() > 1):
+        world = dist.get_world_size(group)
+        z1, z2 = all_gather_with_grad(z1, group), all_gather_with_grad(z2, group)
+    labels = torch.arange(z1.shape[0], device=z1.device)
+    l_c = 0.5 * (F.cross_entropy(z1 @ z2.t() / temperature, labels) + F.cross_entropy(z2 @ z1.t() / temperature, labels))
+
+    l_m = torch.zeros((), device=f_orig.device)
+    if heads.denoise_head is not None and tokens is not None:
+        masked, mask = StructuredTemporalMasking.future_masking(tokens, num_temporal_patches, 0.5)
+        keep = ~mask
+        pooled = (masked * keep.unsqueeze(-1)).sum(dim=1) / keep.sum(dim=1, keepdim=True).clamp_min(1)
+        l_m = F.mse_loss(heads.denoise_head(pooled), tokens.mean(dim=1))
+    if world > 1:
+        w = shard_weight(b_local, z1.shape[0], world)
+        objective = w * (l_t + lambda_mask * l_m) + world * l_c
+    else:
+        objective = l_t + l_c + lambda_mask * l_m
+    return objective, (l_t.detach(), l_c.detach(), l_m.detach())
+
+
 def stage1_losses(model, heads: Stage1Heads, video, video_aug, shuffled_video, order_label,
                   lambda_mask: float = 0.1, temperature: float = 0.07, fuse_views: bool = True,
                   encoder_grad: bool = True, group: Optional[dist.ProcessGroup] = None):
-    """Returns (total, (temporal, contrastive, mask)).  `fuse_views` runs the three gradient-carrying views
-    as ONE encoder pass over 3B clips (clips are independent, so the result is identical and every weight
-    is read once instead of three times).  With `group` set, the InfoNCE negatives span the global batch."""
+    """Returns (objective, (temporal, contrastive, mask)); see `stage1_head_losses` for the objective.  `fuse_views`
+    runs the three gradient-carrying views as ONE encoder pass over 3B clips (clips are independent, so the result is
+    identical and every weight is read once instead of three times)."""
     B = video.shape[0]
     with torch.set_grad_enabled(encoder_grad and torch.is_grad_enabled()):
         if fuse_views:
@@ -49,45 +83,42 @@ def stage1_losses(model, heads: Stage1Heads, video, video_aug, shuffled_video, o
             f_shuf = model.encode_video(shuffled_video).mean(dim=1)
             f_orig = model.encode_video(video).mean(dim=1)
             f_aug = model.encode_video(video_aug).mean(dim=1)
-    l_t = F.cross_entropy(heads.temporal_classifier(f_shuf), order_label)
-
-    z1 = F.normalize(heads.contrastive_proj(f_orig), dim=1)
-    z2 = F.normalize(heads.contrastive_proj(f_aug), dim=1)
-    world = 1
-    if group is not None or (dist.is_initialized() and dist.get_world_size() > 1):
-        world = dist.get_world_size(group)
-        z1, z2 = all_gather_with_grad(z1, group), all_gather_with_grad(z2, group)
-    labels = torch.arange(z1.shape[0], device=z1.device)
-    l_c = 0.5 * (F.cross_entropy(z1 @ z2.t() / temperature, labels) + F.cross_entropy(z2 @ z1.t() / temperature, labels))
-
-    l_m = torch.zeros((), device=video.device)
+    tokens = None
     if heads.denoise_head is not None:
         with torch.no_grad():
             tokens = model.encode_video(video)
-            Tp = model.encoder.tubelet_embed.num_temporal_patches
-            masked, mask = StructuredTemporalMasking.future_masking(tokens, Tp, 0.5)
-        keep = ~mask
-        pooled = (masked * keep.unsqueeze(-1)).sum(dim=1) / keep.sum(dim=1, keepdim=True).clamp_min(1)
-        l_m = F.mse_loss(heads.denoise_head(pooled), tokens.mean(dim=1))
-    # the gathered InfoNCE term is the same number on every rank while gradients are averaged over ranks
-    total = l_t + world * l_c + lambda_mask * l_m if world > 1 else l_t + l_c + lambda_mask * l_m
-    return total, (l_t.detach(), l_c.detach(), l_m.detach())
+    Tp = model.encoder.tubelet_embed.num_temporal_patches
+    return stage1_head_losses(heads, f_shuf, f_orig, f_aug, tokens, Tp, order_label, lambda_mask, temperature, group)
 
 
 def stage1_step(model, heads: Stage1Heads, optimizer, batch: Dict[str, torch.Tensor],
-                max_norm: Optional[float] = 1.0, **kw) -> Tuple[float, Tuple[torch.Tensor, ...]]:
+                max_norm: Optional[float] = 1.0, reducer=None, lambda_mask: float = 0.1,
+                **kw) -> Tuple[float, Tuple[torch.Tensor, ...]]:
     """One optimisation step (s1:418-470).  `optimizer` is a torch optimizer (then the gradients are clipped here
     with clip_grad_norm_) or a `vit_amd.optim.FusedAdamW` built with `max_grad_norm` (clipping happens inside its
-    update kernel: pass max_norm=None)."""
+    update kernel: pass max_norm=None).
+
+    Data parallel: pass the `BucketReducer`.  The encoder's gradients are averaged bucket by bucket inside backward
+    when the reducer is attached to it (`encoder.set_grad_reducer`); every other trained parameter (the heads; the
+    encoder too if the reducer is not attached) is averaged here as one more bucket, and only then -- when every
+    rank holds the same gradients -- is the global norm taken and the step made, so replicas stay identical.
+    Returns the unscaled loss l_t + l_c + lambda*l_m of this rank's shard for logging."""
     optimizer.zero_grad(set_to_none=True)
-    loss, parts = stage1_losses(model, heads, batch["video"], batch["video_augmented"], batch["shuffled_video"],
-                                batch["order_label"].long(), **kw)
-    loss.backward()
+    objective, parts = stage1_losses(model, heads, batch["video"], batch["video_augmented"], batch["shuffled_video"],
+                                     batch["order_label"].long(), lambda_mask=lambda_mask, **kw)
+    objective.backward()
+    trained = [p for g in optimizer.param_groups for p in g["params"]]
+    if reducer is not None:
+        enc = getattr(model, "encoder", None)
+        covered = set()
+        if enc is not None and getattr(enc, "_grad_reducer", None) is reducer:
+            covered = {id(p) for p in enc.parameters()}
+        reducer.reduce_gradients([p for p in trained if id(p) not in covered])
     if max_norm is not None:
-        params = [p for g in optimizer.param_groups for p in g["params"]]
-        torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm)
+        torch.nn.utils.clip_grad_norm_(trained, max_norm=max_norm)
     optimizer.step()
-    return float(loss.detach()), parts
+    l_t, l_c, l_m = parts
+    return float(l_t + l_c + lambda_mask * l_m), parts
 
 
 def jepa_latent_step(encoder, target_encoder, video: torch.Tensor, target_idx: torch.Tensor,
