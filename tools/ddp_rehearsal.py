@@ -1,8 +1,10 @@
 """Two (or more) ranks sharing ONE GPU over gloo: exercises broadcast, the bucket reducer's stream hand-over and the
 gradient agreement across ranks with real kernels when only one device is available (RCCL refuses ranks that share
-a device).  Launch with torch.distributed.run.  Sizes come from DEPTH / IMG / FRAMES / BATCH; keep them small: gloo's
-device-tensor path stalls once a step has tens of 50-MB buckets outstanding (seen at depth 24), which says nothing
-about the RCCL path the real runs use."""
+a device).  Launch with torch.distributed.run.  Sizes come from DEPTH / IMG / FRAMES / BATCH.  Device buffers are
+never handed to gloo: parameters and gradient buckets are staged through host memory by vit_amd.ddp.  A stall
+dumps every thread's Python stack after STALL_SECONDS (faulthandler) and every bucket is logged, so a hang names
+its frame and its bucket."""
+import faulthandler
 import os
 import sys
 import time
@@ -19,6 +21,7 @@ def say(*a):
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    faulthandler.dump_traceback_later(int(os.environ.get("STALL_SECONDS", "150")), exit=True)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo")
@@ -30,14 +33,10 @@ def main():
     torch.manual_seed(42 + rank)          # different on purpose: the broadcast must make them equal
     enc = swm.VideoViTEncoder(img_size=img, num_frames=frames, embed_dim=1024, depth=depth, num_heads=16).eval().to(dev)
     say("model built")
-    for i, p in enumerate(enc.parameters()):
-        host = p.data.cpu()              # through host memory: gloo's device-tensor path stalls on many large tensors
-        dist.broadcast(host, src=0)
-        p.data.copy_(host)
-        if i % 50 == 0:
-            say("broadcast", i)
+    from vit_amd.ddp import broadcast_parameters
+    broadcast_parameters(enc)
     say("broadcast done")
-    reducer = BucketReducer()
+    reducer = BucketReducer(log=say if os.environ.get("BUCKET_LOG", "1") == "1" else None)
     enc.set_grad_reducer(reducer)
     video = torch.randn(batch, 3, frames, img, img, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
     for step in range(2):
@@ -54,6 +53,7 @@ def main():
     assert all(torch.equal(b, both[0]) for b in both), "ranks disagree on the averaged gradients"
     dist.barrier()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
     say("ok")
 
 
