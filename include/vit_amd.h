@@ -101,6 +101,19 @@ int va_layernorm_bwd_dropout(const void* dy, int dy_bf16, const float* x, const 
                              float* dgamma, float* dbeta, int64_t M, int64_t D, uint32_t key, float p,
                              float* copy_colsum, va_stream_t stream);
 
+/* va_layernorm_bwd_dropout without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE:
+ * it exists for callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  The partial sums live in a static device array of the library (6 MiB per GPU,
+ * held until the process ends; rows beyond VA_LN_NOALLOC_MAX_ROWS are rejected with VA_ERR_INVALID_ARG).  Results are
+ * bit-identical to va_layernorm_bwd_dropout.  The library calls no hipMalloc / hipFree here; the first call on each
+ * device resolves that device's array address (make that call outside graph capture).  All calls on one GPU share
+ * the array: calls that overlap on one GPU (different streams, different threads) race -- serialise them. */
+#define VA_LN_NOALLOC_MAX_ROWS (1ll << 20)
+int va_layernorm_bwd_noalloc(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                             const float* rstd, const float* resid_grad, float* dx_out, void* dx_bf16, float* dgamma,
+                             float* dbeta, int64_t M, int64_t D, uint32_t key, float p, float* copy_colsum,
+                             va_stream_t stream);
+
 /* ---- 3D rotary embedding (swm:33-51, 265-281) ------------------------------------------------------
  * In-place rotation of the Q and K thirds of a packed qkv buffer [M, 3*D] bf16 (D = 1024, column
  * segments t:0-255, h:256-639, w:640-1023; partner of column i inside a segment of width d is i+d/2).

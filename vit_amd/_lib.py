@@ -35,6 +35,7 @@ SIGNATURES = {
     "va_layernorm_bwd_partial_rows": (i64, [i64]),
     "va_layernorm_bwd": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp]),
     "va_layernorm_bwd_dropout": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, cu32, cf, vp, vp]),
+    "va_layernorm_bwd_noalloc": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, cu32, cf, vp, vp]),
     "va_rope3d_qk_inplace": (ci, [vp, vp, i64, i64, i64, i64, ci, vp]),
     "va_rope3d_qk_indexed": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, ci, vp]),
     "va_attn_fwd": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp]),

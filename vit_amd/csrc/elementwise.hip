@@ -2,6 +2,7 @@
 // gather, parameter casts, bias-gradient column sums, token masking / gather / scatter, EMA update and
 // the L1 latent loss.  All of them move 16 bytes per lane per access and keep no state.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -660,6 +661,49 @@ extern "C" int va_layernorm_bwd(const void* dy, int dy_bf16, const float* x, con
                                 float* partial, float* dgamma, float* dbeta, int64_t M, int64_t D, hipStream_t stream) {
     return va_layernorm_bwd_dropout(dy, dy_bf16, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, partial, dgamma, dbeta,
                                     M, D, 0u, 0.f, nullptr, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc): the partial-sum workspace is a file-scope device array instead of a caller buffer.
+// The array exists once per GPU the library runs on (6 MiB each, held until the process ends); its address on a
+// device is resolved once, with that device current, and kept in `ln_scratch_ptr`.  Host code never uses the array's
+// name for anything else: on the host the name is only a handle for hipGetSymbolAddress, not a device address.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int VA_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[LN_BWD_BLOCKS * 3 * LN_D];
+static float* ln_scratch_ptr[VA_MAX_DEVICES];
+static std::mutex ln_scratch_lock;
+
+extern "C" int va_layernorm_bwd_noalloc(const void* dy, int dy_bf16, const float* x, const float* gamma,
+                                        const float* mean, const float* rstd, const float* resid_grad, float* dx_out,
+                                        void* dx_bf16, float* dgamma, float* dbeta, int64_t M, int64_t D, uint32_t key,
+                                        float p, float* copy_colsum, hipStream_t stream) {
+    VA_CHECK_ARG(M <= VA_LN_NOALLOC_MAX_ROWS, "va_layernorm_bwd_noalloc: M=%lld rows exceed the maximum of %lld of the no-allocation variant",
+                 (long long)M, (long long)VA_LN_NOALLOC_MAX_ROWS);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VA_MAX_DEVICES) {
+        va_set_error("va_layernorm_bwd_noalloc: no current device (or device index %d beyond %d)", dev, VA_MAX_DEVICES - 1);
+        return VA_ERR_INVALID;
+    }
+    float* ptr;
+    {
+        std::lock_guard<std::mutex> hold(ln_scratch_lock);
+        if (ln_scratch_ptr[dev] == nullptr) {      // first call on this device: resolve this device's copy of the array
+            void* addr = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&addr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || addr == nullptr) {
+                va_set_error("va_layernorm_bwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+                return VA_ERR_LAUNCH;
+            }
+            ln_scratch_ptr[dev] = (float*)addr;
+        }
+        ptr = ln_scratch_ptr[dev];
+    }
+    // every partial row the reduce kernel reads is written by the first kernel of the same call: nothing in the
+    // array has to start at zero, and what the previous call left behind is never read
+    return va_layernorm_bwd_dropout(dy, dy_bf16, x, gamma, mean, rstd, resid_grad, dx_out, dx_bf16, ptr, dgamma, dbeta, M, D,
+                                    key, p, copy_colsum, stream);
 }
 
 extern "C" int va_rope3d_qk_inplace(void* qkv, const float* tables, int64_t M, int64_t Tp, int64_t Hp, int64_t Wp,
