@@ -238,11 +238,7 @@ def gen_predictor():
 
 
 def gen_masking():
-    for m in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
-        sys.modules.setdefault(m, types.ModuleType(m))
-    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
-    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
-    import stage1_surgvu_pretraining as s1  # the reference script (dataset classes unused)
+    s1 = _import_reference_stage1()
     out = {}
     for Tp in (4, 5, 8, 32):
         for ratio in (0.5, 0.75, 0.9):
@@ -284,7 +280,111 @@ def gen_masking():
     save("stage1_losses.npz", total=total.item(), l_t=l_t.item(), l_c=l_c.item(), l_m=l_m.item(), label=label.numpy())
 
 
+def _import_reference_stage1():
+    for m in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    import stage1_surgvu_pretraining as s1  # the reference script (dataset classes unused)
+    return s1
+
+
+def stage1_loop_batch(B=4):
+    """The one synthetic batch of the stage-1 loop fixture (regenerated from names by the tests)."""
+    shape = (B, 3, 4, 32, 32)
+    return {"video": R.hashed_uniform("golden.s1loop.video", shape, 1.0),
+            "video_augmented": R.hashed_uniform("golden.s1loop.aug", shape, 1.0),
+            "shuffled_video": R.hashed_uniform("golden.s1loop.shuf", shape, 1.0),
+            "order_label": torch.tensor([1, 0, 0, 1][:B])}
+
+
+def _manifest(obj):
+    """Nested keys / shapes / dtypes of a checkpoint dictionary (no values)."""
+    if torch.is_tensor(obj):
+        return {"tensor": list(obj.shape), "dtype": str(obj.dtype).replace("torch.", "")}
+    if isinstance(obj, dict):
+        return {"dict": {str(k): _manifest(v) for k, v in obj.items()}}
+    if isinstance(obj, (list, tuple)):
+        return {"list": [_manifest(v) for v in obj]}
+    return {"value": type(obj).__name__}
+
+
+def gen_stage1_loop():
+    """Run the REFERENCE's own training loop, `train_stage1_surgvu` (stage1_surgvu_pretraining.py:340-530), for one
+    epoch of one batch on the CPU: list-backed loader, every nn.Dropout made the identity for the duration (the
+    loop calls model.train()), seeded head initialisation.  Twice: with learning rate 0 (the saved heads are then
+    the initial heads, which certifies that a seed reproduces them) and with the default 4e-4 (post-step weights).
+    Commits the loss the loop wrote into `checkpoint_epoch_01.pth`, samples of the post-step weights, and a manifest
+    (nested keys, shapes, dtypes) of both checkpoint files the loop writes."""
+    import json
+    import tempfile
+    s1 = _import_reference_stage1()
+    SEED, B = 123, 4
+
+    class ListLoader(list):
+        batch_size = B
+
+    def run(lr):
+        model = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                                        predictor_depth=1, predictor_heads=8)
+        model.encoder.load_state_dict(R.fill_state_dict_(model.encoder.state_dict()))
+        out = tempfile.mkdtemp(prefix="s1loop_")
+        keep = torch.nn.Dropout.forward
+        torch.nn.Dropout.forward = lambda self, x: x
+        try:
+            torch.manual_seed(SEED)                       # the loop builds its heads from this stream
+            s1.train_stage1_surgvu(model, ListLoader([stage1_loop_batch(B)]), num_epochs=1, device="cpu", save_dir=out,
+                                   learning_rate=lr)
+        finally:
+            torch.nn.Dropout.forward = keep
+        return (torch.load(os.path.join(out, "checkpoint_epoch_01.pth"), weights_only=True),
+                torch.load(os.path.join(out, "best_encoder_surgvu.pth"), weights_only=True))
+
+    frozen, _ = run(0.0)
+    stepped, best = run(4e-4)
+    assert frozen["loss"] == stepped["loss"]
+    # (1) a seed reproduces the loop's head initialisation in the layer order the product's Stage1Heads uses
+    from vit_amd.train_step import Stage1Heads
+    torch.manual_seed(SEED)
+    mine = Stage1Heads(1024)
+    for part in ("temporal_classifier", "contrastive_proj", "denoise_head"):
+        for k, v in getattr(mine, part).state_dict().items():
+            assert torch.equal(v, frozen[part][k]), (part, k)
+    enc0 = R.fill_state_dict_(stepped["encoder_state_dict"])
+    for k, v in frozen["encoder_state_dict"].items():
+        assert torch.equal(v, enc0[k]), k
+    # (2) the oracle's restatement of the step math gives the loop's loss
+    batch = stage1_loop_batch(B)
+    P = {k: v for k, v in enc0.items() if "inv_freq" not in k}
+    f = [R.encoder_forward(P, batch[k], 1, 16) for k in ("shuffled_video", "video", "video_augmented", "video")]
+    heads = {f"{part}.{k}": v for part in ("temporal_classifier", "contrastive_proj", "denoise_head")
+             for k, v in frozen[part].items()}
+    total, parts = R.stage1_losses(f[0], f[1], f[2], f[3], batch["order_label"], heads, Tp=2)
+    close(total.detach(), torch.tensor(stepped["loss"]), "stage-1 loop loss (oracle vs reference loop)", atol=1e-5)
+
+    arrs = dict(loss=stepped["loss"], seed=SEED, batch=B, lr=4e-4, weight_decay=0.1,
+                l_parts=np.array([float(v) for v in parts]))
+    for name, t in (("encoder.blocks.0.attn.qkv_proj.weight", stepped["encoder_state_dict"]["blocks.0.attn.qkv_proj.weight"]),
+                    ("encoder.blocks.0.mlp.3.bias", stepped["encoder_state_dict"]["blocks.0.mlp.3.bias"]),
+                    ("encoder.norm.weight", stepped["encoder_state_dict"]["norm.weight"]),
+                    ("temporal_classifier.3.weight", stepped["temporal_classifier"]["3.weight"]),
+                    ("contrastive_proj.2.weight", stepped["contrastive_proj"]["2.weight"]),
+                    ("denoise_head.3.weight", stepped["denoise_head"]["3.weight"])):
+        flat = t.reshape(-1).double()
+        rng = np.random.default_rng(R._name_seed(name) % (1 << 32))
+        pos = np.sort(rng.integers(0, flat.numel(), size=min(256, flat.numel())))
+        arrs[f"w:{name}:pos"], arrs[f"w:{name}:val"] = pos.astype(np.int64), flat[pos].numpy()
+    save("stage1_loop.npz", **arrs)
+    with open(os.path.join(HERE, "stage1_checkpoint_manifest.json"), "w") as fh:
+        json.dump({"checkpoint_epoch_01.pth": _manifest(stepped), "best_encoder_surgvu.pth": _manifest(best)}, fh, indent=1,
+                  sort_keys=False)
+    print("wrote stage1_checkpoint_manifest.json")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "stage1_loop":  # only the loop fixture
+        gen_stage1_loop()
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "predictor":     # only the predictor fixture
         gen_predictor()
         raise SystemExit(0)
@@ -296,4 +396,5 @@ if __name__ == "__main__":
         gen_encoder()
         gen_seed_canary()
         gen_masking()
+        gen_stage1_loop()
     print("all golden vectors written")

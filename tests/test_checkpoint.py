@@ -45,6 +45,29 @@ def test_stage1_layouts(tmp_path):
     assert C.load_checkpoint(tmp_path / "b.pth")["denoise_head"] is None
 
 
+def test_stage1_files_have_the_manifest_of_the_reference_loops_files(tmp_path, golden_dir):
+    """stage1_checkpoint_manifest.json lists the nested keys, shapes and dtypes of the two files the reference's own
+    loop wrote (s1:498-523) for a depth-1 model.  The files this package writes -- with torch's AdamW as in the
+    reference, and with FusedAdamW in its place -- must have the same structure."""
+    import json
+    import os
+    from conftest import checkpoint_manifest
+    want = json.load(open(os.path.join(golden_dir, "stage1_checkpoint_manifest.json")))
+    model, heads = tiny_model(predictor_depth=1), Stage1Heads()
+    params = list(model.encoder.parameters()) + list(heads.parameters())
+    opt = torch.optim.AdamW(params, lr=4e-4, weight_decay=0.1)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=1)
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    sched.step()
+    C.save_stage1_checkpoint(tmp_path / "checkpoint_epoch_01.pth", 1, model, heads, 2.3, opt, sched)
+    C.save_stage1_checkpoint(tmp_path / "best_encoder_surgvu.pth", 1, model, heads, 2.3)
+    for name in ("checkpoint_epoch_01.pth", "best_encoder_surgvu.pth"):
+        got = checkpoint_manifest(C.load_checkpoint(tmp_path / name))
+        assert got == want[name], name
+
+
 def test_finetune_layout(tmp_path):
     model, heads = tiny_model(), Stage1Heads()
     opt = torch.optim.AdamW(heads.parameters(), lr=1e-4)

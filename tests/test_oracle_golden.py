@@ -107,6 +107,23 @@ def test_stage1_losses(golden_dir):
     np.testing.assert_allclose([l_t.item(), l_c.item(), l_m.item()], [g["l_t"], g["l_c"], g["l_m"]], rtol=1e-5)
 
 
+def test_stage1_loss_of_the_reference_training_loop(golden_dir):
+    """stage1_loop.npz holds the loss the REFERENCE's own loop (`train_stage1_surgvu`, s1:340-530) wrote into
+    checkpoint_epoch_01.pth for one batch: heads initialised from torch.manual_seed(seed) inside the loop, encoder on
+    the closed-form weights, dropout disabled.  The oracle's restatement of the step math must give that number."""
+    from conftest import stage1_loop_batch
+    from vit_amd.train_step import Stage1Heads
+    g = _load(golden_dir, "stage1_loop.npz")
+    torch.manual_seed(int(g["seed"]))
+    heads = {k: v for k, v in Stage1Heads(1024).state_dict().items()}       # same layer order = same random stream
+    batch = stage1_loop_batch(int(g["batch"]))
+    P = R.make_encoder_params(1)
+    f = [R.encoder_forward(P, batch[k], 1, 16) for k in ("shuffled_video", "video", "video_augmented", "video")]
+    total, parts = R.stage1_losses(f[0], f[1], f[2], f[3], batch["order_label"], heads, Tp=2)
+    np.testing.assert_allclose(total.item(), float(g["loss"]), rtol=2e-6)
+    np.testing.assert_allclose([float(v) for v in parts], g["l_parts"], rtol=2e-5)
+
+
 def test_jepa_masks_are_seeded_and_disjoint():
     c1, t1 = R.jepa_block_masks(7, 4, (8, 16, 16))
     c2, t2 = R.jepa_block_masks(7, 4, (8, 16, 16))

@@ -105,3 +105,66 @@ def test_jepa_latent_step(env):
     assert (tg_flat.flat.cpu() - ref_ema).abs().max().item() < 1e-6
     with torch.no_grad():                        # the target encoder computes with the updated weights
         assert not torch.equal(target(video).cpu(), z_tg)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_stage1_step_against_the_reference_training_loop(env, golden_dir, tmp_path, fused):
+    """One step of the reference's own loop (`train_stage1_surgvu`, s1:340-530, run on the CPU by
+    tests/golden/make_golden.py: one batch, seeded heads, dropout off, AdamW 4e-4 / 0.1, clip 1.0): the loss it saved
+    and samples of the weights after its optimizer step.  The device step runs with torch.optim.AdamW +
+    clip_grad_norm_ as the reference does, and with FusedAdamW (clip inside the update kernel).
+
+    Tolerances: loss 1e-2 relative (bf16 encoder).  After ONE AdamW step every weight has moved by about
+    lr * sign(gradient): a sampled weight must match the reference's to 5 % of lr, except where a tiny gradient's
+    sign is decided by bf16 rounding -- at most 5 % of the samples may differ by up to 2 lr."""
+    import json
+    import os
+    import numpy as np
+    from conftest import checkpoint_manifest, stage1_loop_batch
+    from vit_amd import checkpoint
+    from vit_amd.optim import FusedAdamW
+    swm, ts, _, _ = env
+    g = np.load(os.path.join(golden_dir, "stage1_loop.npz"), allow_pickle=False)
+    lr = float(g["lr"])
+    model = small_model(swm)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    torch.manual_seed(int(g["seed"]))
+    heads = ts.Stage1Heads(1024)
+    heads.temporal_classifier[2].p = 0.0
+    heads = heads.cuda()
+    model.train()
+    heads.train()
+    params = list(model.encoder.parameters()) + list(heads.parameters())
+    if fused:
+        opt = FusedAdamW(params, lr=lr, weight_decay=float(g["weight_decay"]), max_grad_norm=1.0)
+    else:
+        opt = torch.optim.AdamW(params, lr=lr, weight_decay=float(g["weight_decay"]))
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=1)
+    batch = {k: v.cuda() for k, v in stage1_loop_batch(int(g["batch"])).items()}
+    loss, parts = ts.stage1_step(model, heads, opt, batch, max_norm=None if fused else 1.0, fuse_views=not fused)
+    sched.step()
+    assert abs(loss - float(g["loss"])) < 1e-2 * float(g["loss"]), (loss, float(g["loss"]))
+    np.testing.assert_allclose([float(v) for v in parts], g["l_parts"], rtol=3e-2, atol=2e-3)
+    named = {"encoder." + k: v for k, v in model.encoder.state_dict().items()}
+    named.update({f"{part}.{k}": v for part in ("temporal_classifier", "contrastive_proj", "denoise_head")
+                  for k, v in getattr(heads, part).state_dict().items()})
+    for key in g.files:
+        if not key.endswith(":pos"):
+            continue
+        name = key[2:-4]
+        got = named[name].reshape(-1).double().cpu()[torch.from_numpy(g[key])]
+        diff = (got - torch.from_numpy(g[f"w:{name}:val"])).abs()
+        assert diff.max().item() <= 2.05 * lr, name
+        assert (diff > 0.05 * lr).double().mean().item() <= 0.05, (name, (diff > 0.05 * lr).double().mean().item())
+    # the file written after the step has the structure of the file the reference's loop wrote
+    checkpoint.save_stage1_checkpoint(tmp_path / "ck.pth", 1, model, heads, loss, opt, sched)
+    got = checkpoint_manifest(checkpoint.load_checkpoint(tmp_path / "ck.pth"))
+    want = json.load(open(os.path.join(golden_dir, "stage1_checkpoint_manifest.json")))["checkpoint_epoch_01.pth"]
+    if fused:        # torch's AdamW carries implementation switches (amsgrad, foreach, fused ...) FusedAdamW has no use for
+        keep = {"lr", "betas", "eps", "weight_decay", "initial_lr", "params"}
+        for side in (got, want):
+            grp = side["dict"]["optimizer"]["dict"]["param_groups"]["list"][0]["dict"]
+            side["dict"]["optimizer"]["dict"]["param_groups"]["list"][0]["dict"] = {k: v for k, v in grp.items() if k in keep}
+    assert got == want
