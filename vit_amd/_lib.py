@@ -15,7 +15,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint32, c_void_p
 import torch  # noqa: F401  (import order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvit_amd.so")
+# VIT_AMD_LIB=<path> loads another build of the same library (same-box A/B of kernel variants); there is still no fallback.
+LIB_PATH = os.environ.get("VIT_AMD_LIB") or os.path.join(_HERE, "libvit_amd.so")
 
 _lib = None
 
