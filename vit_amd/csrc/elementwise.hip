@@ -3,6 +3,7 @@
 // the L1 latent loss.  All of them move 16 bytes per lane per access and keep no state.
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 
@@ -457,72 +458,99 @@ __global__ __launch_bounds__(256) void token_move_kernel(const u32x4_t* __restri
 // ------------------------------------------------------------------------------------------------
 // EMA and L1
 // ------------------------------------------------------------------------------------------------
+// UNROLL independent 16-byte pieces per stream are requested before the first is used (a thread keeps
+// 2 * UNROLL * 16 bytes in flight); the streams are touched once, so loads and stores carry the non-temporal hint.
+template <int UNROLL>
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tgt, const float* __restrict__ onl,
                                                   bf16_t* __restrict__ shadow, int64_t n, float m) {
     const float om = 1.0f - m;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
-        if (i + 4 <= n) {
-            const f32x4_t t = *(const f32x4_t*)(tgt + i);
-            const f32x4_t o = *(const f32x4_t*)(onl + i);
-            const f32x4_t r = {m * t[0] + om * o[0], m * t[1] + om * o[1], m * t[2] + om * o[2], m * t[3] + om * o[3]};
-            *(f32x4_t*)(tgt + i) = r;
-            if (shadow) *(u32x2_t*)(shadow + i) = (u32x2_t){pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
-        } else {
-            for (int64_t j = i; j < n; ++j) {
-                const float r = m * tgt[j] + om * onl[j];
-                tgt[j] = r;
-                if (shadow) shadow[j] = f32_to_bf16(r);
+    const int64_t step = (int64_t)gridDim.x * 1024 * UNROLL;
+    for (int64_t i0 = ((int64_t)blockIdx.x * UNROLL * 256 + threadIdx.x) * 4; i0 < n; i0 += step) {
+        f32x4_t t[UNROLL], o[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t i = i0 + (int64_t)u * 1024;
+            if (i + 4 <= n) {
+                t[u] = __builtin_nontemporal_load((const f32x4_t*)(tgt + i));
+                o[u] = __builtin_nontemporal_load((const f32x4_t*)(onl + i));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t i = i0 + (int64_t)u * 1024;
+            if (i + 4 <= n) {
+                const f32x4_t r = {m * t[u][0] + om * o[u][0], m * t[u][1] + om * o[u][1], m * t[u][2] + om * o[u][2],
+                                   m * t[u][3] + om * o[u][3]};
+                __builtin_nontemporal_store(r, (f32x4_t*)(tgt + i));
+                if (shadow) *(u32x2_t*)(shadow + i) = (u32x2_t){pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+            } else if (i < n) {
+                for (int64_t j = i; j < n; ++j) {
+                    const float r = m * tgt[j] + om * onl[j];
+                    tgt[j] = r;
+                    if (shadow) shadow[j] = f32_to_bf16(r);
+                }
             }
         }
     }
 }
 
+// A thread handles L1_CHUNKS pieces of 8 elements per iteration, all of their loads requested before the first use.
+constexpr int L1_CHUNKS = 4;
 template <bool IN_BF16, bool GRAD_BF16>
 __global__ __launch_bounds__(256) void l1_kernel(const void* __restrict__ pred, const void* __restrict__ tgt,
                                                  float* __restrict__ loss_sum, void* __restrict__ grad, float gscale,
                                                  int64_t n) {
     __shared__ float red[4];
     float acc = 0.f;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 2048) {
-        float p[8], t[8], g[8];
-        const int cnt = (n - i) >= 8 ? 8 : (int)(n - i);
-        if (cnt == 8) {
-            if (IN_BF16) {
-                unpack8(*(const u32x4_t*)((const bf16_t*)pred + i), p);
-                unpack8(*(const u32x4_t*)((const bf16_t*)tgt + i), t);
+    const int64_t step = (int64_t)gridDim.x * 2048 * L1_CHUNKS;
+    for (int64_t i0 = ((int64_t)blockIdx.x * L1_CHUNKS * 256 + threadIdx.x) * 8; i0 < n; i0 += step) {
+        float p[L1_CHUNKS][8], t[L1_CHUNKS][8];
+#pragma unroll
+        for (int u = 0; u < L1_CHUNKS; ++u) {
+            const int64_t i = i0 + (int64_t)u * 2048;
+            if (i + 8 <= n) {
+                if (IN_BF16) {
+                    unpack8(__builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)pred + i)), p[u]);
+                    unpack8(__builtin_nontemporal_load((const u32x4_t*)((const bf16_t*)tgt + i)), t[u]);
+                } else {
+                    *(f32x4_t*)(p[u]) = __builtin_nontemporal_load((const f32x4_t*)((const float*)pred + i));
+                    *(f32x4_t*)(p[u] + 4) = __builtin_nontemporal_load((const f32x4_t*)((const float*)pred + i + 4));
+                    *(f32x4_t*)(t[u]) = __builtin_nontemporal_load((const f32x4_t*)((const float*)tgt + i));
+                    *(f32x4_t*)(t[u] + 4) = __builtin_nontemporal_load((const f32x4_t*)((const float*)tgt + i + 4));
+                }
             } else {
-                *(f32x4_t*)(p) = *(const f32x4_t*)((const float*)pred + i);
-                *(f32x4_t*)(p + 4) = *(const f32x4_t*)((const float*)pred + i + 4);
-                *(f32x4_t*)(t) = *(const f32x4_t*)((const float*)tgt + i);
-                *(f32x4_t*)(t + 4) = *(const f32x4_t*)((const float*)tgt + i + 4);
-            }
-        } else {
-            for (int j = 0; j < 8; ++j) {
-                p[j] = 0.f;
-                t[j] = 0.f;
-                if (j < cnt) {
-                    p[j] = IN_BF16 ? bf16_to_f32(((const bf16_t*)pred)[i + j]) : ((const float*)pred)[i + j];
-                    t[j] = IN_BF16 ? bf16_to_f32(((const bf16_t*)tgt)[i + j]) : ((const float*)tgt)[i + j];
+                for (int j = 0; j < 8; ++j) {
+                    p[u][j] = 0.f;
+                    t[u][j] = 0.f;
+                    if (i + j < n) {
+                        p[u][j] = IN_BF16 ? bf16_to_f32(((const bf16_t*)pred)[i + j]) : ((const float*)pred)[i + j];
+                        t[u][j] = IN_BF16 ? bf16_to_f32(((const bf16_t*)tgt)[i + j]) : ((const float*)tgt)[i + j];
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float d = p[j] - t[j];
-            acc += fabsf(d);
-            g[j] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
-        }
-        if (grad != nullptr) {
-            if (cnt == 8) {
-                if (GRAD_BF16) *(u32x4_t*)((bf16_t*)grad + i) = pack8(g);
-                else {
-                    *(f32x4_t*)((float*)grad + i) = *(f32x4_t*)(g);
-                    *(f32x4_t*)((float*)grad + i + 4) = *(f32x4_t*)(g + 4);
-                }
-            } else {
-                for (int j = 0; j < cnt; ++j) {
-                    if (GRAD_BF16) ((bf16_t*)grad)[i + j] = f32_to_bf16(g[j]);
-                    else ((float*)grad)[i + j] = g[j];
+        for (int u = 0; u < L1_CHUNKS; ++u) {
+            const int64_t i = i0 + (int64_t)u * 2048;
+            float g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = p[u][j] - t[u][j];
+                acc += fabsf(d);
+                g[j] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+            }
+            if (grad != nullptr) {
+                if (i + 8 <= n) {
+                    if (GRAD_BF16) __builtin_nontemporal_store(pack8(g), (u32x4_t*)((bf16_t*)grad + i));
+                    else {
+                        __builtin_nontemporal_store(*(f32x4_t*)(g), (f32x4_t*)((float*)grad + i));
+                        __builtin_nontemporal_store(*(f32x4_t*)(g + 4), (f32x4_t*)((float*)grad + i + 4));
+                    }
+                } else {
+                    for (int j = 0; j < 8 && i + j < n; ++j) {
+                        if (GRAD_BF16) ((bf16_t*)grad)[i + j] = f32_to_bf16(g[j]);
+                        else ((float*)grad)[i + j] = g[j];
+                    }
                 }
             }
         }
@@ -848,9 +876,10 @@ extern "C" int va_ema_update(float* target, const float* online, void* target_bf
                              hipStream_t stream) {
     VA_CHECK_ARG(target && online && n > 0, "va_ema_update: null or empty operand");
     VA_CHECK_ARG(((uintptr_t)target | (uintptr_t)online | (uintptr_t)target_bf16) % 16 == 0, "va_ema_update: misaligned operand");
-    unsigned blocks = blocks_for(n, 1024);
+    constexpr int UNROLL = 4;     // measured on 303.8 M parameters: 1 -> 4.8 TB/s, 2 -> 5.7, 4 -> 6.05
+    unsigned blocks = blocks_for(n, 1024 * UNROLL);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(ema_kernel, dim3(blocks), dim3(256), 0, stream, target, online, (bf16_t*)target_bf16, n, momentum);
+    hipLaunchKernelGGL(ema_kernel<UNROLL>, dim3(blocks), dim3(256), 0, stream, target, online, (bf16_t*)target_bf16, n, momentum);
     VA_CHECK_LAUNCH("va_ema_update");
     return VA_OK;
 }
@@ -863,8 +892,11 @@ extern "C" int va_l1_loss(const void* pred, const void* target, int in_bf16, flo
         va_set_error("va_l1_loss: memset failed");
         return VA_ERR_LAUNCH;
     }
-    unsigned blocks = blocks_for(n, 2048);
-    if (blocks > 8192) blocks = 8192;
+    // every block ends with one atomic add onto the same word, and same-address float atomics serialise at the
+    // memory side: few, long-running blocks keep that tail short
+    // (measured at 67 M bf16 elements: 8192 blocks 123 us, 1024 blocks 77 us, 256 blocks 139 us)
+    unsigned blocks = blocks_for(n, 2048 * L1_CHUNKS);
+    if (blocks > 1024) blocks = 1024;
 #define VA_L1(IB, GB) hipLaunchKernelGGL((l1_kernel<IB, GB>), dim3(blocks), dim3(256), 0, stream, pred, target, loss_sum, grad, grad_scale, n)
     if (in_bf16) { if (grad_bf16) VA_L1(true, true); else VA_L1(true, false); }
     else { if (grad_bf16) VA_L1(false, true); else VA_L1(false, false); }
