@@ -1,6 +1,6 @@
 """Join tools/hbm_kernels.py's algorithmic bytes with rocprofv3's kernel stats and FETCH_SIZE / WRITE_SIZE passes.
 usage: hbm_table.py <log with the JSON line> <kernel_stats.csv> <FETCH counter csv> <WRITE counter csv> <out.csv>
-FETCH_SIZE is doubled (gfx950 reports half the bytes of wide streaming reads); both counters are in KiB-like units of 1000 B."""
+FETCH_SIZE is doubled (gfx950 reports half the bytes of wide streaming reads); both counters are reported in KiB."""
 import collections, csv, json, re, sys
 log, stats_p, f_p, w_p, out_p = sys.argv[1:6]
 alg = json.loads(re.findall(r'\{.*\}', open(log).read())[-1])
@@ -21,6 +21,6 @@ for key, nbytes in alg.items():
     n = pick(stats, kname); avg = float(stats[n]['AverageNs'])
     fk = pick(F, kname)
     lines.append(f"\"{key}\",{stats[n]['Calls']},{avg / 1e3:.1f},{nbytes},{nbytes / avg:.0f},{nbytes / avg / 8000:.3f},"
-                 f"{F[fk] * 2e3 if fk else 0:.0f},{W[fk] * 1e3 if fk else 0:.0f}")
+                 f"{F[fk] * 2048 if fk else 0:.0f},{W[fk] * 1024 if fk else 0:.0f}")
 open(out_p, 'w').write("\n".join(lines) + "\n")
 print("\n".join(lines))
