@@ -142,6 +142,31 @@ def test_full_size_properties(swm):
         assert rel(p.grad, g1[k]) < 1e-4, k      # f32 atomics in the weight-gradient GEMM reorder sums
 
 
+def test_deterministic_mode_gives_bit_identical_gradients(swm):
+    """ops.set_deterministic(True): one workgroup per weight-gradient tile and bias sums without unordered atomics, so
+    two backward passes agree bit for bit (the default mode agrees to ~1e-6: f32 atomics reorder the sums), and the
+    two modes agree with each other to f32 rounding."""
+    from vit_amd import ops
+    enc = build(swm, 2, 16, 8, 64)
+    video = R.hashed_uniform("test.video.det", (3, 3, 8, 64, 64), 1.0).cuda()
+
+    def grads():
+        enc.zero_grad(set_to_none=True)
+        (enc(video) ** 2).mean().backward()
+        return {k: p.grad.clone() for k, p in enc.named_parameters()}
+
+    base = grads()
+    assert not ops.is_deterministic()
+    ops.set_deterministic(True)
+    try:
+        a, b = grads(), grads()
+    finally:
+        ops.set_deterministic(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        assert rel(a[k], base[k]) < 1e-5, k
+
+
 def test_frozen_encoder_and_world_model_forward(swm):
     m = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=8, encoder_depth=2, encoder_heads=16,
                                                 predictor_depth=3, predictor_heads=8).eval().cuda()

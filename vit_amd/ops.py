@@ -2,6 +2,7 @@
 HIP stream across the boundary.  Nothing here computes; torch is used for memory and streams only."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -72,9 +73,43 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, epilogue: int, out: torch.Tensor, 
     return out
 
 
+# Weight gradients are summed over slices of the token dimension with f32 atomics, so their last bits depend on the
+# order in which workgroups finish.  In deterministic mode every output tile is produced by ONE workgroup (one slice:
+# a single add per element onto the incoming value) and bias gradients come from the same kernel run against a column
+# of ones, so two runs give bit-identical gradients -- at several times the cost of the weight-gradient GEMMs.  A debug
+# switch (run-twice comparisons, bisecting), not a training mode.
+_deterministic = os.environ.get("VIT_AMD_DETERMINISTIC", "0") == "1"
+_ones_cache = {}
+
+
+def set_deterministic(on: bool) -> None:
+    global _deterministic
+    _deterministic = bool(on)
+
+
+def is_deterministic() -> bool:
+    return _deterministic
+
+
+def _ones_column(M: int, device) -> torch.Tensor:
+    key = (M, str(device))
+    t = _ones_cache.get(key)
+    if t is None:
+        _ones_cache.clear()                      # one size at a time: the buffer is M x 128 bf16
+        t = _ones_cache[key] = torch.ones(M, 128, dtype=BF16, device=device)
+    return t
+
+
 def gemm_tn_accum(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor] = None,
                   split_k: int = 0) -> torch.Tensor:
     """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]; optionally dbias[N] (f32) += dy.sum(0) in the same pass."""
+    if _deterministic:
+        split_k = 1
+        if dbias is not None:
+            sums = torch.zeros(dy.shape[1], 128, dtype=F32, device=dy.device)
+            gemm_tn_accum(dy, _ones_column(dy.shape[0], dy.device), sums, None)
+            dbias.add_(sums[:, 0])
+            dbias = None
     _need(dy, BF16, "dy"); _need(x, BF16, "x"); _need(dw, F32, "dw")
     M, N = dy.shape
     M2, K = x.shape
