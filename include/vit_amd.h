@@ -209,6 +209,19 @@ int va_token_gather(const void* x, const int32_t* idx, void* out, int64_t B, int
 int va_token_scatter(const void* src, const int32_t* idx, void* out, int64_t B, int64_t N_dst, int64_t N_keep,
                      int64_t row_bytes, va_stream_t stream);
 
+/* ---- token pooling of the stage-1 heads (stage1_surgvu_pretraining.py:426, 431-432 `encode_video(...).mean(dim=1)`;
+ * :452-460 the mean over the tokens future_masking leaves unmasked) ------------------------------------------------
+ * out[b][d] = scale * sum over tokens n < n_first of x[b][n][d];  x f32 [B, N, D], out f32 [B, D], D % 4 == 0.
+ * n_first = N, scale = 1/N is the plain mean; n_first = cutoff * tokens_per_timestep, scale = 1/max(n_first, 1) is the
+ * masked mean (future_masking masks a suffix of the token axis), computed without materialising the zero-filled copy.
+ * workspace: va_token_pool_workspace_floats(B, D) floats.  Fixed summation order (bitwise reproducible).
+ * The backward writes dx[b][n][:] = n < n_first ? scale * g[b][:] : 0. */
+int64_t va_token_pool_workspace_floats(int64_t B, int64_t D);
+int va_token_pool_fwd(const float* x, float* out, float* workspace, int64_t B, int64_t N, int64_t D, int64_t n_first,
+                      float scale, va_stream_t stream);
+int va_token_pool_bwd(const float* g, float* dx, int64_t B, int64_t N, int64_t D, int64_t n_first, float scale,
+                      va_stream_t stream);
+
 /* ---- EMA target update and L1 latent loss (no reference symbol; JEPA objective pieces) -----------------
  * target <- m*target + (1-m)*online over n f32 elements; optional bf16 shadow of the new target. */
 int va_ema_update(float* target, const float* online, void* target_bf16, int64_t n, float momentum,

@@ -131,8 +131,14 @@ class _StandInModel(torch.nn.Module):
 def _stage1_setup(seed):
     from vit_amd import train_step as ts
     from oracle import ref_cpu as R
-    # the masking kernel needs a device; on CPU the oracle's restatement of the same function stands in (test only)
-    ts.StructuredTemporalMasking = type("M", (), {"future_masking": staticmethod(R.future_masking)})
+    # the pooling kernels need a device; on CPU a torch restatement (mean / the oracle's future_masking + masked mean,
+    # s1:449-460) stands in for them -- test only, what is under test here is the reduction semantics across ranks
+    def pool_unmasked(tokens, Tp, ratio=0.5):
+        masked, mask = R.future_masking(tokens, Tp, ratio)
+        keep = ~mask
+        return (masked * keep.unsqueeze(-1)).sum(dim=1) / keep.sum(dim=1, keepdim=True).clamp_min(1), tokens.mean(dim=1)
+    ts._pool_tokens = lambda x: x.mean(dim=1)
+    ts._pool_unmasked = pool_unmasked
     torch.manual_seed(seed)
     model = _StandInModel()
     heads = ts.Stage1Heads(dim=32).eval()              # eval: the classifier's nn.Dropout(0.1) is the identity

@@ -396,3 +396,40 @@ def test_multi_cast_plan(ops, dev):
     assert torch.equal(dst[0], srcs[0].to(BF16)) and torch.equal(dst_t[0], srcs[0].t().contiguous().to(BF16))
     with pytest.raises(ValueError):
         ops.CastPlan([(rnd((100, 64), dev, 1), None, None)])
+
+
+@pytest.mark.parametrize("B,N,D,n_first", [(3, 37, 1024, None), (2, 64, 128, 32), (4, 2048, 1024, 1024), (2, 8, 1024, 0), (1, 5, 4, 5)])
+def test_token_pool_forward_backward(B, N, D, n_first):
+    """The pooling of the stage-1 heads: `.mean(dim=1)` (s1:426-432) and the mean over the tokens future_masking leaves
+    unmasked (s1:452-460: zero-fill, multiply by the keep mask, divide by clamp_min(count, 1)) against the oracle's
+    future_masking; the backward against autograd.  Tolerance: f32 summation order (1e-5)."""
+    from vit_amd import ops
+    x = R.hashed_uniform(f"pool.x.{B}.{N}.{D}", (B, N, D), 1.0)
+    got = ops.token_pool(x.cuda(), n_first)
+    xr = x.clone().requires_grad_(True)
+    if n_first is None:
+        ref = xr.mean(dim=1)
+    else:
+        keep = torch.zeros(B, N, dtype=torch.bool)
+        keep[:, :n_first] = True
+        masked = xr * keep.unsqueeze(-1)                        # the zero-filled copy of future_masking
+        ref = (masked * keep.unsqueeze(-1)).sum(dim=1) / keep.sum(dim=1, keepdim=True).clamp_min(1)
+    assert torch.allclose(got.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(got, ops.token_pool(x.cuda(), n_first))          # fixed summation order
+    g = R.hashed_uniform("pool.g", (B, D), 1.0)
+    (ref * g).sum().backward()
+    dx = ops.token_pool_bwd(g.cuda(), N, n_first)
+    assert torch.allclose(dx.cpu(), xr.grad, rtol=1e-6, atol=1e-7)
+
+
+def test_masked_pool_matches_future_masking_of_the_oracle():
+    from vit_amd import ops
+    from vit_amd.masking import StructuredTemporalMasking as STM
+    for Tp, per_t, ratio in ((8, 6, 0.5), (5, 4, 0.5), (8, 3, 0.9), (4, 8, 0.75)):
+        x = R.hashed_uniform("pool.fm", (2, Tp * per_t, 64), 1.0)
+        masked, mask = R.future_masking(x, Tp, ratio)
+        keep = ~mask
+        ref = (masked * keep.unsqueeze(-1)).sum(dim=1) / keep.sum(dim=1, keepdim=True).clamp_min(1)
+        n_first = STM.first_masked_row(Tp * per_t, Tp, ratio)
+        assert n_first == int(keep[0].sum())
+        assert torch.allclose(ops.token_pool(x.cuda(), n_first).cpu(), ref, rtol=1e-5, atol=1e-6)

@@ -53,6 +53,9 @@ SIGNATURES = {
     "va_future_mask": (ci, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "va_token_gather": (ci, [vp, vp, vp, i64, i64, i64, i64, vp]),
     "va_token_scatter": (ci, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    "va_token_pool_workspace_floats": (i64, [i64, i64]),
+    "va_token_pool_fwd": (ci, [vp, vp, vp, i64, i64, i64, i64, cf, vp]),
+    "va_token_pool_bwd": (ci, [vp, vp, i64, i64, i64, i64, cf, vp]),
     "va_ema_update": (ci, [vp, vp, vp, i64, cf, vp]),
     "va_l1_loss": (ci, [vp, vp, ci, vp, vp, ci, cf, i64, vp]),
     "va_normalize_u8": (ci, [vp, vp, i64, i64, i64, i64, vp, vp, vp]),

@@ -561,6 +561,61 @@ __global__ __launch_bounds__(256) void l1_kernel(const void* __restrict__ pred, 
     if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Token pooling of the stage-1 heads (stage1_surgvu_pretraining.py:426-432 `.mean(dim=1)`, :456-460 the mean over the
+// unmasked tokens): out[b][d] = scale * sum_{n < n_first} x[b][n][d] over x f32 [B, N, D], D % 4 == 0.
+// Stage 1: block (b, part) sums a contiguous run of rows into partial[b][part][:] (a thread owns 4 columns, fixed
+// order).  Stage 2: the parts are added in index order.  No atomics: bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+constexpr int POOL_PARTS = 64;
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int N,
+                                                           int D, int n_first) {
+    const int b = blockIdx.x / POOL_PARTS, part = blockIdx.x % POOL_PARTS;
+    const int per = (n_first + POOL_PARTS - 1) / POOL_PARTS;
+    const int r0 = part * per, r1 = min(n_first, r0 + per);
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        const float* col = x + ((int64_t)b * N) * D + c;
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {             // eight rows requested before the first is added
+            f32x4_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load((const f32x4_t*)(col + (int64_t)(r + u) * D));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; r < r1; ++r) acc += *(const f32x4_t*)(col + (int64_t)r * D);
+        *(f32x4_t*)(partial + ((int64_t)blockIdx.x) * D + c) = acc;
+    }
+}
+__global__ __launch_bounds__(256) void pool_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                          int64_t BD, int D, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= BD) return;
+    const int64_t b = i / D, d = i % D;
+    float a = 0.f;
+#pragma unroll
+    for (int p = 0; p < POOL_PARTS; ++p) a += partial[(b * POOL_PARTS + p) * D + d];
+    out[i] = a * scale;
+}
+// backward: dx[b][n][:] = n < n_first ? scale * g[b][:] : 0   (a write-only stream)
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int64_t total4,
+                                                       int N, int D, int n_first, float scale) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x);
+    if (i >= total4) return;
+    const int d4 = D / 4;
+    const int64_t row = i / d4;
+    const int c = (int)(i % d4) * 4;
+    const int64_t b = row / N;
+    const int n = (int)(row % N);
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (n < n_first) {
+        v = *(const f32x4_t*)(g + b * D + c);
+        v *= scale;
+    }
+    __builtin_nontemporal_store(v, (f32x4_t*)(dx + row * D + c));
+}
+
 inline unsigned blocks_for(int64_t items, int per_block) { return (unsigned)((items + per_block - 1) / per_block); }
 
 // uint8 frames [B, T, H, W, 3] -> f32 clip [B, 3, T, H, W], (u / 255 - mean[c]) / std[c] with the same three
@@ -870,6 +925,35 @@ extern "C" int va_token_gather(const void* x, const int32_t* idx, void* out, int
 extern "C" int va_token_scatter(const void* src, const int32_t* idx, void* out, int64_t B, int64_t N_dst,
                                 int64_t N_keep, int64_t row_bytes, hipStream_t stream) {
     return token_move(true, src, idx, out, B, N_dst, N_keep, row_bytes, stream, "va_token_scatter");
+}
+
+extern "C" int64_t va_token_pool_workspace_floats(int64_t B, int64_t D) { return B > 0 && D > 0 ? B * POOL_PARTS * D : 0; }
+
+extern "C" int va_token_pool_fwd(const float* x, float* out, float* workspace, int64_t B, int64_t N, int64_t D,
+                                 int64_t n_first, float scale, hipStream_t stream) {
+    VA_CHECK_ARG(x && out && workspace, "va_token_pool_fwd: null operand");
+    VA_CHECK_ARG(B > 0 && N > 0 && D > 0 && D % 4 == 0 && N < (1ll << 31) && B * POOL_PARTS < (1ll << 31), "va_token_pool_fwd: bad shape");
+    VA_CHECK_ARG(n_first >= 0 && n_first <= N, "va_token_pool_fwd: n_first=%lld outside [0, N]", (long long)n_first);
+    VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace) % 16 == 0, "va_token_pool_fwd: misaligned operand");
+    hipLaunchKernelGGL(pool_partial_kernel, dim3((unsigned)(B * POOL_PARTS)), dim3(256), 0, stream, x, workspace, (int)N, (int)D,
+                       (int)n_first);
+    VA_CHECK_LAUNCH("va_token_pool_fwd");
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3(blocks_for(B * D, 256)), dim3(256), 0, stream, workspace, out, B * D, (int)D, scale);
+    VA_CHECK_LAUNCH("va_token_pool_fwd(reduce)");
+    return VA_OK;
+}
+
+extern "C" int va_token_pool_bwd(const float* g, float* dx, int64_t B, int64_t N, int64_t D, int64_t n_first, float scale,
+                                 hipStream_t stream) {
+    VA_CHECK_ARG(g && dx, "va_token_pool_bwd: null operand");
+    VA_CHECK_ARG(B > 0 && N > 0 && D > 0 && D % 4 == 0 && N < (1ll << 31), "va_token_pool_bwd: bad shape");
+    VA_CHECK_ARG(n_first >= 0 && n_first <= N, "va_token_pool_bwd: n_first=%lld outside [0, N]", (long long)n_first);
+    VA_CHECK_ARG(((uintptr_t)g | (uintptr_t)dx) % 16 == 0, "va_token_pool_bwd: misaligned operand");
+    const int64_t total4 = B * N * D / 4;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(total4, 256)), dim3(256), 0, stream, g, dx, total4, (int)N, (int)D,
+                       (int)n_first, scale);
+    VA_CHECK_LAUNCH("va_token_pool_bwd");
+    return VA_OK;
 }
 
 extern "C" int va_ema_update(float* target, const float* online, void* target_bf16, int64_t n, float momentum,

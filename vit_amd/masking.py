@@ -18,6 +18,14 @@ from . import ops
 
 class StructuredTemporalMasking:
     @staticmethod
+    def first_masked_row(n_tokens: int, num_temporal_patches: int, mask_ratio: float = 0.5) -> int:
+        """Index of the first masked token: cutoff * tokens-per-timestep with cutoff = int(T * (1 - ratio)) (s1:318)."""
+        per_t = n_tokens // num_temporal_patches
+        if num_temporal_patches * per_t != n_tokens:
+            raise ValueError("N must be a whole number of timesteps")
+        return int(num_temporal_patches * (1 - mask_ratio)) * per_t
+
+    @staticmethod
     def future_masking(encoded_features: torch.Tensor, num_temporal_patches: int, mask_ratio: float = 0.5):
         """(B,N,D) -> (masked features, bool mask (B,N), True = masked).  All tokens of timesteps
         >= int(T*(1-ratio)) are zeroed; the cut-off is deterministic and equal for every batch row."""

@@ -482,6 +482,35 @@ def token_scatter(src: torch.Tensor, idx: torch.Tensor, n_tokens: int) -> torch.
     return out
 
 
+def token_pool(x: torch.Tensor, n_first: Optional[int] = None) -> torch.Tensor:
+    """Mean over the first n_first tokens of x f32 (B, N, D) -> (B, D); n_first=None pools all tokens (`.mean(dim=1)`).
+    n_first = 0 gives zeros (the reference's clamp_min(count, 1) denominator)."""
+    _need(x, F32, "x")
+    if x.dim() != 3 or not x.is_contiguous() or x.shape[2] % 4:
+        raise ValueError("token_pool: x must be a contiguous (B, N, D) f32 tensor with D a multiple of 4")
+    B, N, D = x.shape
+    n_first = N if n_first is None else int(n_first)
+    lib = _lib.load()
+    out = torch.empty(B, D, dtype=F32, device=x.device)
+    ws = torch.empty(lib.va_token_pool_workspace_floats(B, D), dtype=F32, device=x.device)
+    check(lib.va_token_pool_fwd(_p(x), _p(out), _p(ws), B, N, D, n_first, 1.0 / max(n_first, 1), _stream()),
+          "va_token_pool_fwd")
+    return out
+
+
+def token_pool_bwd(g: torch.Tensor, n_tokens: int, n_first: Optional[int] = None) -> torch.Tensor:
+    """Gradient of `token_pool` with respect to x: (B, D) -> (B, N, D)."""
+    _need(g, F32, "g")
+    if g.dim() != 2 or not g.is_contiguous():
+        raise ValueError("token_pool_bwd: g must be a contiguous (B, D) f32 tensor")
+    B, D = g.shape
+    n_first = n_tokens if n_first is None else int(n_first)
+    dx = torch.empty(B, n_tokens, D, dtype=F32, device=g.device)
+    check(_lib.load().va_token_pool_bwd(_p(g), _p(dx), B, n_tokens, D, n_first, 1.0 / max(n_first, 1), _stream()),
+          "va_token_pool_bwd")
+    return dx
+
+
 def ema_update_(target: torch.Tensor, online: torch.Tensor, momentum: float, shadow_bf16: Optional[torch.Tensor] = None):
     _need(target, F32, "target"); _need(online, F32, "online")
     if target.numel() != online.numel() or not (target.is_contiguous() and online.is_contiguous()):

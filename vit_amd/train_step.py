@@ -34,11 +34,40 @@ class Stage1Heads(nn.Module):
                              if use_mask_aux else None)
 
 
-def stage1_head_losses(heads: Stage1Heads, f_shuf, f_orig, f_aug, tokens, num_temporal_patches: int, order_label,
+class _TokenPool(torch.autograd.Function):
+    """Mean over the token axis, (B, N, D) -> (B, D): one reduction kernel forward, one broadcast kernel backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.n = x.shape[1]
+        return ops.token_pool(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.token_pool_bwd(g.contiguous(), ctx.n)
+
+
+def _pool_tokens(x: torch.Tensor) -> torch.Tensor:
+    """`x.mean(dim=1)` (s1:426, 431-432) on the pooling kernel."""
+    return _TokenPool.apply(x)
+
+
+def _pool_unmasked(tokens: torch.Tensor, num_temporal_patches: int, mask_ratio: float = 0.5):
+    """(mean over the tokens `future_masking` leaves unmasked, mean over all tokens) of a no-grad pass (s1:449-460).
+    The mask zeroes a suffix of the token axis, so the masked mean is a pooling over the first cutoff * S tokens:
+    neither the zero-filled copy nor the boolean mask is materialised."""
+    per_t = tokens.shape[1] // num_temporal_patches
+    n_first = StructuredTemporalMasking.first_masked_row(tokens.shape[1], num_temporal_patches, mask_ratio)
+    t = tokens.detach().contiguous()
+    return ops.token_pool(t, n_first), ops.token_pool(t)
+
+
+def stage1_head_losses(heads: Stage1Heads, f_shuf, f_orig, f_aug, pooled_unmasked, pooled_all, order_label,
                        lambda_mask: float = 0.1, temperature: float = 0.07,
                        group: Optional[dist.ProcessGroup] = None):
     """The step's loss arithmetic on pooled encoder features (s1:426-465): f_* are (B, D) mean-pooled features of
-    the shuffled / original / augmented views, `tokens` the (B, N, D) no-grad pass (None without the denoise head).
+    the shuffled / original / augmented views; pooled_unmasked / pooled_all the (B, D) means of the no-grad pass over
+    the unmasked tokens and over all tokens (None without the denoise head).
 
     Returns (objective, (l_t, l_c, l_m)).  In a world of one the objective is l_t + l_c + lambda*l_m.  With several
     ranks the InfoNCE negatives span the global batch (projections are all-gathered), and the objective is scaled
@@ -55,11 +84,8 @@ def stage1_head_losses(heads: Stage1Heads, f_shuf, f_orig, f_aug, tokens, num_te
     l_c = 0.5 * (F.cross_entropy(z1 @ z2.t() / temperature, labels) + F.cross_entropy(z2 @ z1.t() / temperature, labels))
 
     l_m = torch.zeros((), device=f_orig.device)
-    if heads.denoise_head is not None and tokens is not None:
-        masked, mask = StructuredTemporalMasking.future_masking(tokens, num_temporal_patches, 0.5)
-        keep = ~mask
-        pooled = (masked * keep.unsqueeze(-1)).sum(dim=1) / keep.sum(dim=1, keepdim=True).clamp_min(1)
-        l_m = F.mse_loss(heads.denoise_head(pooled), tokens.mean(dim=1))
+    if heads.denoise_head is not None and pooled_unmasked is not None:
+        l_m = F.mse_loss(heads.denoise_head(pooled_unmasked), pooled_all)
     if world > 1:
         w = shard_weight(b_local, z1.shape[0], world)
         objective = w * (l_t + lambda_mask * l_m) + world * l_c
@@ -73,22 +99,25 @@ def stage1_losses(model, heads: Stage1Heads, video, video_aug, shuffled_video, o
                   encoder_grad: bool = True, group: Optional[dist.ProcessGroup] = None):
     """Returns (objective, (temporal, contrastive, mask)); see `stage1_head_losses` for the objective.  `fuse_views`
     runs the three gradient-carrying views as ONE encoder pass over 3B clips (clips are independent, so the result is
-    identical and every weight is read once instead of three times)."""
+    identical and every weight is read once instead of three times).  The token pooling on either side of the heads
+    (the only part of them that moves more than a few megabytes) runs on the pooling kernels; the heads' small
+    (B x 1024) layers are library GEMMs through torch."""
     B = video.shape[0]
     with torch.set_grad_enabled(encoder_grad and torch.is_grad_enabled()):
         if fuse_views:
-            feats = model.encode_video(torch.cat([shuffled_video, video, video_aug], dim=0)).mean(dim=1)
+            feats = _pool_tokens(model.encode_video(torch.cat([shuffled_video, video, video_aug], dim=0)))
             f_shuf, f_orig, f_aug = feats[:B], feats[B:2 * B], feats[2 * B:]
         else:
-            f_shuf = model.encode_video(shuffled_video).mean(dim=1)
-            f_orig = model.encode_video(video).mean(dim=1)
-            f_aug = model.encode_video(video_aug).mean(dim=1)
-    tokens = None
+            f_shuf = _pool_tokens(model.encode_video(shuffled_video))
+            f_orig = _pool_tokens(model.encode_video(video))
+            f_aug = _pool_tokens(model.encode_video(video_aug))
+    pooled_unmasked = pooled_all = None
     if heads.denoise_head is not None:
         with torch.no_grad():
             tokens = model.encode_video(video)
-    Tp = model.encoder.tubelet_embed.num_temporal_patches
-    return stage1_head_losses(heads, f_shuf, f_orig, f_aug, tokens, Tp, order_label, lambda_mask, temperature, group)
+            pooled_unmasked, pooled_all = _pool_unmasked(tokens, model.encoder.tubelet_embed.num_temporal_patches)
+    return stage1_head_losses(heads, f_shuf, f_orig, f_aug, pooled_unmasked, pooled_all, order_label, lambda_mask,
+                              temperature, group)
 
 
 def stage1_step(model, heads: Stage1Heads, optimizer, batch: Dict[str, torch.Tensor],
