@@ -381,7 +381,55 @@ def gen_stage1_loop():
     print("wrote stage1_checkpoint_manifest.json")
 
 
+def gen_pretrained_manifest():
+    """The reference's writer and reader of the adapted-checkpoint file: `save_adapted_checkpoint`
+    (load_vjepa2_pretrained.py:279-300) writes a reference model -> manifest committed; the reference's
+    `load_pretrained_model` (stage1_vjepa2_finetuning.py:57-138) then loads a file written by THIS package's
+    `checkpoint.save_pretrained_model` and every tensor must come back equal (interchange in the direction the
+    tests cannot run without the reference)."""
+    import json
+    import tempfile
+    _import_reference_stage1()
+    import load_vjepa2_pretrained as lp          # the reference (its network code is never called)
+    import stage1_vjepa2_finetuning as ft        # the reference
+    out = tempfile.mkdtemp(prefix="lp_")
+    cfg = {"embed_dim": 1024, "depth": 1, "num_heads": 16}
+    ref_model = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                                        predictor_depth=2, predictor_heads=8)
+    ref_model.load_state_dict(R.fill_state_dict_(ref_model.state_dict()))
+    lp.save_adapted_checkpoint(ref_model, os.path.join(out, "ref.pth"), cfg, {"source": "test"})
+    man = _manifest(torch.load(os.path.join(out, "ref.pth"), weights_only=True))
+    with open(os.path.join(HERE, "pretrained_checkpoint_manifest.json"), "w") as fh:
+        json.dump(man, fh, indent=1)
+    print("wrote pretrained_checkpoint_manifest.json")
+
+    from vit_amd import checkpoint as C
+    from vit_amd import surgical_world_model as mine
+    my_model = mine.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                                        predictor_depth=2, predictor_heads=8)
+    my_model.load_state_dict(R.fill_state_dict_(my_model.state_dict()))
+    C.save_pretrained_model(my_model, os.path.join(out, "mine.pth"), cfg, {"source": "test"})
+    loaded, config = ft.load_pretrained_model(os.path.join(out, "mine.pth"), img_size=32, num_frames=4, predictor_depth=2,
+                                              device="cpu")
+    assert config == {"encoder_dim": 1024, "encoder_depth": 1, "encoder_heads": 16}
+    ref_sd, got_sd = ref_model.state_dict(), loaded.state_dict()
+    assert list(ref_sd) == list(got_sd)
+    for k in ref_sd:
+        assert torch.equal(ref_sd[k], got_sd[k]), k
+    print(f"  ok the reference's load_pretrained_model read this package's file: {len(ref_sd)} tensors equal")
+    # and the other direction: this package reads the reference writer's file
+    mine_loaded, my_cfg = C.load_pretrained_model(os.path.join(out, "ref.pth"), img_size=32, num_frames=4, predictor_depth=2,
+                                                  device="cpu")
+    assert my_cfg == config and not mine_loaded.load_result.missing_keys and not mine_loaded.load_result.unexpected_keys
+    for k, v in mine_loaded.state_dict().items():
+        assert torch.equal(v, ref_sd[k]), k
+    print("  ok this package's load_pretrained_model read the reference writer's file")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pretrained":
+        gen_pretrained_manifest()
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stage1_loop":  # only the loop fixture
         gen_stage1_loop()
         raise SystemExit(0)
@@ -397,4 +445,5 @@ if __name__ == "__main__":
         gen_seed_canary()
         gen_masking()
         gen_stage1_loop()
+        gen_pretrained_manifest()
     print("all golden vectors written")

@@ -68,6 +68,20 @@ def test_stage1_files_have_the_manifest_of_the_reference_loops_files(tmp_path, g
         assert got == want[name], name
 
 
+def test_pretrained_file_has_the_manifest_of_the_reference_writers_file(tmp_path, golden_dir):
+    """pretrained_checkpoint_manifest.json: nested keys / shapes / dtypes of the file the reference's own
+    `save_adapted_checkpoint` (load_vjepa2_pretrained.py:279-300) wrote for a depth-1 model with a two-block
+    predictor.  (The fixture script also had the reference's `load_pretrained_model`, ft:57-138, load a file written by
+    this package and compared every tensor.)"""
+    import json
+    import os
+    from conftest import checkpoint_manifest
+    want = json.load(open(os.path.join(golden_dir, "pretrained_checkpoint_manifest.json")))
+    model = tiny_model(depth=1, predictor_depth=2)
+    C.save_pretrained_model(model, tmp_path / "p.pth", {"embed_dim": 1024, "depth": 1, "num_heads": 16}, {"source": "test"})
+    assert checkpoint_manifest(C.load_checkpoint(tmp_path / "p.pth")) == want
+
+
 def test_finetune_layout(tmp_path):
     model, heads = tiny_model(), Stage1Heads()
     opt = torch.optim.AdamW(heads.parameters(), lr=1e-4)
@@ -85,15 +99,17 @@ def test_pretrained_round_trip_and_defaults(tmp_path):
     C.save_pretrained_model(model, tmp_path / "p.pth", {"embed_dim": 1024, "depth": 2, "num_heads": 16}, {"src": "t"})
     ck = C.load_checkpoint(tmp_path / "p.pth")
     assert list(ck) == ["model_state_dict", "encoder_state_dict", "vjepa2_config", "metadata"]
-    loaded, res = C.load_pretrained_model(tmp_path / "p.pth", img_size=32, num_frames=4, predictor_depth=2, device="cpu")
+    loaded, cfg = C.load_pretrained_model(tmp_path / "p.pth", img_size=32, num_frames=4, predictor_depth=2, device="cpu")
+    assert cfg == {"encoder_dim": 1024, "encoder_depth": 2, "encoder_heads": 16}            # ft:132-136
+    res = loaded.load_result
     assert res.missing_keys == [] and res.unexpected_keys == []
     for (k, a), (_, b) in zip(model.state_dict().items(), loaded.state_dict().items()):
         assert torch.equal(a, b), k
     assert loaded.use_grad_checkpoint is True
     # encoder-only file, different predictor depth: strict=False leaves the predictor at its initial values
     torch.save({"encoder_state_dict": ck["encoder_state_dict"], "vjepa2_config": {"depth": 2}}, tmp_path / "e.pth")
-    enc_only, res = C.load_pretrained_model(tmp_path / "e.pth", img_size=32, num_frames=4, predictor_depth=1, device="cpu")
-    assert res.missing_keys == [] and len(enc_only.predictor_blocks) == 1
+    enc_only, cfg = C.load_pretrained_model(tmp_path / "e.pth", img_size=32, num_frames=4, predictor_depth=1, device="cpu")
+    assert cfg["encoder_heads"] == 16 and enc_only.load_result.missing_keys == [] and len(enc_only.predictor_blocks) == 1
     assert torch.equal(enc_only.encoder.blocks[1].mlp[0].weight, model.encoder.blocks[1].mlp[0].weight)
     # the config defaults are the V-JEPA2 ViT-L numbers
     assert C.VJEPA2_DEFAULTS == {"embed_dim": 1024, "depth": 24, "num_heads": 16}

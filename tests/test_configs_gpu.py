@@ -164,8 +164,9 @@ def test_config4_depth40_8192_tokens_properties_and_checkpoint(swm, tmp_path):
 
     path = tmp_path / "vjepa2_vitg.pth"
     checkpoint.save_pretrained_model(model, path, {"embed_dim": 1024, "depth": 40, "num_heads": 16})
-    loaded, result = checkpoint.load_pretrained_model(path, img_size=256, num_frames=64, predictor_depth=1)
-    assert not result.missing_keys and not result.unexpected_keys
+    loaded, cfg = checkpoint.load_pretrained_model(path, img_size=256, num_frames=64, predictor_depth=1)
+    assert cfg == {"encoder_dim": 1024, "encoder_depth": 40, "encoder_heads": 16}
+    assert not loaded.load_result.missing_keys and not loaded.load_result.unexpected_keys
     assert len(loaded.encoder.blocks) == 40
     with torch.no_grad():
         assert torch.equal(loaded.eval().encoder(video), y0)

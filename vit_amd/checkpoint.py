@@ -74,10 +74,13 @@ def load_checkpoint(path) -> Dict[str, Any]:
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
-def load_pretrained_model(path, img_size: int = 256, num_frames: int = 16, predictor_dim: int = 1024,
+def load_pretrained_model(path, img_size: int = 224, num_frames: int = 16, predictor_dim: int = 1024,
                           predictor_depth: int = 12, predictor_heads: int = 8, device="cuda"):
-    """ft:84-128: build the model from the file's `vjepa2_config` (defaults 1024/24/16) and load its weights with
-    strict=False: the full model when `model_state_dict` is present, else the encoder alone."""
+    """stage1_vjepa2_finetuning.py:57-138, same signature and return value: build the model from the file's
+    `vjepa2_config` (defaults 1024/24/16) and load its weights with strict=False -- the full model when
+    `model_state_dict` is present, else the encoder alone.  Returns (model, config) with config =
+    {encoder_dim, encoder_depth, encoder_heads}; what `load_state_dict` reported (missing / unexpected keys) is kept on
+    the model as `model.load_result`."""
     ckpt = load_checkpoint(path)
     cfg = {**VJEPA2_DEFAULTS, **(ckpt.get("vjepa2_config") or {})}
     model = SurgicalActionConditionedWorldModel(
@@ -91,4 +94,6 @@ def load_pretrained_model(path, img_size: int = 256, num_frames: int = 16, predi
         result = model.encoder.load_state_dict(ckpt["encoder_state_dict"], strict=False)
     else:
         raise ValueError("Checkpoint does not contain model weights")
-    return model.to(device), result
+    model = model.to(device)
+    model.load_result = result
+    return model, {"encoder_dim": cfg["embed_dim"], "encoder_depth": cfg["depth"], "encoder_heads": cfg["num_heads"]}
