@@ -167,6 +167,22 @@ def test_deterministic_mode_gives_bit_identical_gradients(swm):
         assert rel(a[k], base[k]) < 1e-5, k
 
 
+def test_refresh_weights_after_a_write_through_data(swm):
+    """`p.data.mul_()` does not bump the version counter the operand cache keys on: the stale bf16 copies are used
+    until `refresh_weights()` is called (documented on the method)."""
+    enc = build(swm, 1, 16, 4, 32)
+    video = R.hashed_uniform("test.video.refresh", (1, 3, 4, 32, 32), 1.0).cuda()
+    with torch.no_grad():
+        y0 = enc(video).clone()
+        enc.blocks[0].mlp[3].weight.data.mul_(0.5)
+        enc.refresh_weights()
+        y1 = enc(video)
+        enc.blocks[0].mlp[3].weight.mul_(2.0)            # an ordinary in-place op is noticed by itself
+        y2 = enc(video)
+    assert not torch.equal(y0, y1)
+    assert torch.equal(y0, y2)
+
+
 def test_frozen_encoder_and_world_model_forward(swm):
     m = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=8, encoder_depth=2, encoder_heads=16,
                                                 predictor_depth=3, predictor_heads=8).eval().cuda()

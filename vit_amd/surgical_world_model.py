@@ -295,6 +295,14 @@ class VideoViTEncoder(nn.Module):
             self._engine_obj = EncoderEngine(self._cfg)     # raises for head counts without a kernel
         return self._engine_obj
 
+    def refresh_weights(self) -> None:
+        """Drop the cached bf16 operand copies of the weights.  The copies are keyed on each parameter's autograd
+        version counter, which optimizers and in-place tensor methods bump -- but writes through `param.data`
+        (`p.data.copy_(...)`, `p.data.mul_(...)`, the usual EMA idiom) or by a kernel do not.  Call this after such a
+        write (vit_amd's own EMA update and parameter broadcast do)."""
+        if self._engine_obj is not None:
+            self._engine_obj.weights.invalidate()
+
     def set_grad_reducer(self, reducer) -> None:
         """Attach a `vit_amd.ddp.BucketReducer`: gradients are then averaged across ranks inside backward."""
         self._grad_reducer = reducer
