@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     // next one (read by this stage's prefetch) and the barrier tells that every wave has taken the current stage
     // into registers and is done with the previous one, whose slot the stage four ahead refills during this body.
     int slot = 0;                                          // ring slot of the current stage
-    uint64_t t_sync = 0, t_body = 0, t_last = 0;          // DBG 5: cycles in waits+barriers / in stage bodies
+    uint64_t t_sync = 0, t_body = 0, t_epi = 0, t_last = 0;          // DBG 5: cycles in waits+barriers / in stage bodies
     // `relaxed`: the first three stages after the epilogue of a tile whose rows all exist.  Memory operations
     // retire in issue order and the loads of this tile's stages 1..3 went out before the epilogue's stores, so the
     // loads a stage needs are followed by two stages' loads AND those stores (32 instructions per wave for one
@@ -739,6 +739,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 
         // the asm MFMAs are opaque to the compiler's hazard tracking: let the last results retire before they are read
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_body += now - t_last; t_last = now; }
         const bool more = vn < tiles;
         const int ticket = more ? draw() : 0;
         const bool full = cur.m0 + wm * 128 + 128 <= M;
@@ -747,6 +748,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
             if (full) store_tile_wide<EPI, TM, true, HAS_BIAS, true, false>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
             else store_tile_wide<EPI, TM, false, HAS_BIAS, false, false>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
         }
+        if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
         if (!more) break;
         post(before(slot), ticket);
         __builtin_amdgcn_s_barrier();
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     if (DBG == 5 && lane == 0) {
         float* o = (float*)ep.out + ((size_t)blockIdx.x * 4 + wave) * 4;
         const uint64_t now = __builtin_amdgcn_s_memtime();
-        o[0] = (float)t_sync; o[1] = (float)t_body; o[2] = (float)(now - t_last);
+        o[0] = (float)t_sync; o[1] = (float)t_body; o[2] = (float)(now - t_last); o[3] = (float)t_epi;
     }
 #endif
 }
@@ -858,7 +860,10 @@ int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
         if (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] <= 0)
             cus[dev] = 256;
     }
-    const int grid = tiles < cus[dev & 63] ? tiles : cus[dev & 63];
+    int grid = tiles < cus[dev & 63] ? tiles : cus[dev & 63];
+#ifdef VA_GEMM_DEBUG_VARIANTS   // fewer workgroups than CUs: does a tile's epilogue or stage get faster with less company?
+    if (const char* g = getenv("VA_QUAD_GRID")) grid = atoi(g) < grid ? atoi(g) : grid;
+#endif
     bool none = false;
     int* tk = quad_ticket_set(dev, stream, &none);
     if (none) return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
