@@ -381,6 +381,78 @@ def gen_stage1_loop():
     print("wrote stage1_checkpoint_manifest.json")
 
 
+def gen_finetune_loop():
+    """Run the REFERENCE's fine-tuning loop, `train_stage1_with_vjepa2` (stage1_vjepa2_finetuning.py:141-397), for one
+    epoch of one batch on the CPU, with the encoder frozen and unfrozen: same list-backed loader, dropout made the
+    identity, seeded heads.  The loop's optimizer has one group per sub-module (encoder at a tenth of the rate when
+    it trains, ft:196-232) under a warm-up schedule (ft:235-241: the first epoch runs at half the base rate).  Commits
+    the loss in `best_vjepa2_finetuned.pth`, samples of the post-step weights, the group learning rates and a manifest
+    of the file."""
+    import json
+    import tempfile
+    _import_reference_stage1()
+    import stage1_vjepa2_finetuning as ft        # the reference
+    SEED, B, LR = 321, 4, 4e-4
+
+    class ListLoader(list):
+        batch_size = B
+
+    def run(frozen):
+        model = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                                        predictor_depth=1, predictor_heads=8)
+        model.encoder.load_state_dict(R.fill_state_dict_(model.encoder.state_dict()))
+        out = tempfile.mkdtemp(prefix="ftloop_")
+        keep = torch.nn.Dropout.forward
+        torch.nn.Dropout.forward = lambda self, x: x
+        try:
+            torch.manual_seed(SEED)
+            ft.train_stage1_with_vjepa2(model, ListLoader([stage1_loop_batch(B)]), num_epochs=1, device="cpu", save_dir=out,
+                                        learning_rate=LR, encoder_frozen=frozen)
+        finally:
+            torch.nn.Dropout.forward = keep
+        return torch.load(os.path.join(out, "best_vjepa2_finetuned.pth"), weights_only=True)
+
+    arrs = dict(seed=SEED, batch=B, lr=LR, weight_decay=0.1)
+    manifests = {}
+    for frozen in (True, False):
+        ck = run(frozen)
+        tag = "frozen" if frozen else "unfrozen"
+        manifests[tag] = _manifest(ck)
+        enc0 = R.fill_state_dict_(dict(ck["encoder_state_dict"]))
+        if frozen:
+            for k, v in ck["encoder_state_dict"].items():
+                assert torch.equal(v, enc0[k]), k
+        # the loss is a function of the initial weights: the oracle's restatement must give it (heads by seed)
+        from vit_amd.train_step import Stage1Heads
+        torch.manual_seed(SEED)
+        init = Stage1Heads(1024)
+        heads = {f"{part}.{k}": v for part in ("temporal_classifier", "contrastive_proj", "denoise_head")
+                 for k, v in getattr(init, part).state_dict().items()}
+        batch = stage1_loop_batch(B)
+        P = {k: v for k, v in enc0.items() if "inv_freq" not in k}
+        f = [R.encoder_forward(P, batch[k], 1, 16) for k in ("shuffled_video", "video", "video_augmented", "video")]
+        total, parts = R.stage1_losses(f[0], f[1], f[2], f[3], batch["order_label"], heads, Tp=2)
+        close(total.detach(), torch.tensor(ck["loss"]), f"fine-tune loop loss ({tag}; oracle vs reference loop)", atol=1e-5)
+        arrs[f"{tag}:loss"] = ck["loss"]
+        arrs[f"{tag}:l_parts"] = np.array([float(v) for v in parts])
+        arrs[f"{tag}:group_lr"] = np.array([g["lr"] for g in ck["optimizer"]["param_groups"]])
+        arrs[f"{tag}:group_initial_lr"] = np.array([g["initial_lr"] for g in ck["optimizer"]["param_groups"]])
+        arrs[f"{tag}:group_sizes"] = np.array([len(g["params"]) for g in ck["optimizer"]["param_groups"]])
+        for name, t in (("encoder.blocks.0.attn.qkv_proj.weight", ck["encoder_state_dict"]["blocks.0.attn.qkv_proj.weight"]),
+                        ("encoder.norm.weight", ck["encoder_state_dict"]["norm.weight"]),
+                        ("temporal_classifier.3.weight", ck["temporal_classifier"]["3.weight"]),
+                        ("contrastive_proj.2.weight", ck["contrastive_proj"]["2.weight"]),
+                        ("denoise_head.3.weight", ck["denoise_head"]["3.weight"])):
+            flat = t.reshape(-1).double()
+            rng = np.random.default_rng(R._name_seed(name) % (1 << 32))
+            pos = np.sort(rng.integers(0, flat.numel(), size=min(256, flat.numel())))
+            arrs[f"{tag}:w:{name}:pos"], arrs[f"{tag}:w:{name}:val"] = pos.astype(np.int64), flat[pos].numpy()
+    save("finetune_loop.npz", **arrs)
+    with open(os.path.join(HERE, "finetune_checkpoint_manifest.json"), "w") as fh:
+        json.dump(manifests, fh, indent=1, sort_keys=False)
+    print("wrote finetune_checkpoint_manifest.json")
+
+
 def gen_pretrained_manifest():
     """The reference's writer and reader of the adapted-checkpoint file: `save_adapted_checkpoint`
     (load_vjepa2_pretrained.py:279-300) writes a reference model -> manifest committed; the reference's
@@ -430,6 +502,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pretrained":
         gen_pretrained_manifest()
         raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "finetune_loop":
+        gen_finetune_loop()
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stage1_loop":  # only the loop fixture
         gen_stage1_loop()
         raise SystemExit(0)
@@ -445,5 +520,6 @@ if __name__ == "__main__":
         gen_seed_canary()
         gen_masking()
         gen_stage1_loop()
+        gen_finetune_loop()
         gen_pretrained_manifest()
     print("all golden vectors written")

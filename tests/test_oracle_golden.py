@@ -135,3 +135,29 @@ def test_jepa_masks_are_seeded_and_disjoint():
     x = R.hashed_uniform("x", (4, 2048, 16), 1.0)
     back = R.token_scatter(R.token_gather(x, t1), t1, 2048)
     assert torch.equal(R.token_gather(back, t1), R.token_gather(x, t1))
+
+
+def test_finetune_schedule_and_groups_follow_the_reference_loop(golden_dir):
+    """`warmup_cosine` and `finetune_param_groups` against what the reference's fine-tuning loop left in its optimizer
+    (tests/golden/finetune_loop.npz: group sizes and learning rates before and after the first `scheduler.step()`)."""
+    import os
+    import numpy as np
+    import torch
+    from vit_amd import surgical_world_model as swm
+    from vit_amd import train_step as ts
+    g = np.load(os.path.join(golden_dir, "finetune_loop.npz"), allow_pickle=False)
+    lam = ts.warmup_cosine(2, 10)
+    assert [lam(0), lam(1), lam(2)] == [0.5, 1.0, 1.0] and abs(lam(6) - 0.5) < 1e-12 and abs(lam(10)) < 1e-12
+    for frozen in (True, False):
+        tag = "frozen" if frozen else "unfrozen"
+        model = swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                                        predictor_depth=1, predictor_heads=8)
+        heads = ts.Stage1Heads(1024)
+        groups = ts.finetune_param_groups(model, heads, float(g["lr"]), encoder_frozen=frozen)
+        assert [len(x["params"]) for x in groups] == g[f"{tag}:group_sizes"].tolist()
+        np.testing.assert_allclose([x["lr"] for x in groups], g[f"{tag}:group_initial_lr"], rtol=1e-12)
+        assert all(p.requires_grad != frozen for p in model.encoder.parameters())
+        opt = torch.optim.AdamW(groups, weight_decay=0.1)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, ts.warmup_cosine(2, 1))
+        opt.step(); sched.step()
+        np.testing.assert_allclose([x["lr"] for x in opt.param_groups], g[f"{tag}:group_lr"], rtol=1e-12)

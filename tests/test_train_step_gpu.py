@@ -168,3 +168,77 @@ def test_stage1_step_against_the_reference_training_loop(env, golden_dir, tmp_pa
             grp = side["dict"]["optimizer"]["dict"]["param_groups"]["list"][0]["dict"]
             side["dict"]["optimizer"]["dict"]["param_groups"]["list"][0]["dict"] = {k: v for k, v in grp.items() if k in keep}
     assert got == want
+
+
+@pytest.mark.parametrize("frozen", [True, False])
+def test_finetune_step_against_the_reference_loop(env, golden_dir, tmp_path, frozen):
+    """One step of the reference's fine-tuning loop (`train_stage1_with_vjepa2`, ft:141-397, run on the CPU by
+    tests/golden/make_golden.py with the encoder frozen and unfrozen): optimizer groups per sub-module with the
+    encoder at a tenth of the rate, warm-up schedule (the first epoch runs at half the base rate), clip 1.0.
+    Here: `finetune_param_groups` + FusedAdamW + LambdaLR(`warmup_cosine`) + `stage1_step`.  Same tolerances as the
+    pre-training loop's test; with the encoder frozen its weights must not move at all."""
+    import json
+    import os
+    import numpy as np
+    from conftest import checkpoint_manifest, stage1_loop_batch
+    from vit_amd import checkpoint
+    from vit_amd.optim import FusedAdamW
+    swm, ts, _, _ = env
+    tag = "frozen" if frozen else "unfrozen"
+    g = np.load(os.path.join(golden_dir, "finetune_loop.npz"), allow_pickle=False)
+    lr = float(g["lr"])
+    model = small_model(swm)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    torch.manual_seed(int(g["seed"]))
+    heads = ts.Stage1Heads(1024)
+    heads.temporal_classifier[2].p = 0.0
+    heads = heads.cuda()
+    model.train()
+    heads.train()
+    before = {k: v.clone() for k, v in model.encoder.state_dict().items()}
+    groups = ts.finetune_param_groups(model, heads, lr, encoder_frozen=frozen)
+    assert [len(x["params"]) for x in groups] == g[f"{tag}:group_sizes"].tolist()
+    assert model.encoder.training == (not frozen)
+    opt = FusedAdamW(groups, weight_decay=float(g["weight_decay"]), max_grad_norm=1.0)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, ts.warmup_cosine(2, 1))
+    np.testing.assert_allclose([x["initial_lr"] for x in opt.param_groups], g[f"{tag}:group_initial_lr"], rtol=1e-12)
+    step_lrs = [x["lr"] for x in opt.param_groups]
+    np.testing.assert_allclose(step_lrs, 0.5 * g[f"{tag}:group_initial_lr"], rtol=1e-12)      # warm-up, epoch 0
+    batch = {k: v.cuda() for k, v in stage1_loop_batch(int(g["batch"])).items()}
+    loss, parts = ts.stage1_step(model, heads, opt, batch, max_norm=None, encoder_grad=not frozen)
+    sched.step()
+    np.testing.assert_allclose([x["lr"] for x in opt.param_groups], g[f"{tag}:group_lr"], rtol=1e-12)
+    want_loss = float(g[f"{tag}:loss"])
+    assert abs(loss - want_loss) < 1e-2 * want_loss, (loss, want_loss)
+    np.testing.assert_allclose([float(v) for v in parts], g[f"{tag}:l_parts"], rtol=3e-2, atol=2e-3)
+    named = {"encoder." + k: v for k, v in model.encoder.state_dict().items()}
+    named.update({f"{part}.{k}": v for part in ("temporal_classifier", "contrastive_proj", "denoise_head")
+                  for k, v in getattr(heads, part).state_dict().items()})
+    if frozen:
+        for k, v in model.encoder.state_dict().items():
+            assert torch.equal(v, before[k]), k
+    pre = f"{tag}:w:"
+    for key in g.files:
+        if not (key.startswith(pre) and key.endswith(":pos")):
+            continue
+        name = key[len(pre):-4]
+        step_lr = 0.5 * lr * (0.1 if name.startswith("encoder.") else 1.0)
+        got = named[name].reshape(-1).double().cpu()[torch.from_numpy(g[key])]
+        diff = (got - torch.from_numpy(g[f"{pre}{name}:val"])).abs()
+        if frozen and name.startswith("encoder."):
+            assert diff.max().item() == 0.0, name
+            continue
+        assert diff.max().item() <= 2.05 * step_lr, name
+        assert (diff > 0.05 * step_lr).double().mean().item() <= 0.05, (name, (diff > 0.05 * step_lr).double().mean().item())
+    # the file written after the step has the structure of the file the reference's loop wrote
+    checkpoint.save_finetune_checkpoint(tmp_path / "ft.pth", 1, model, heads, loss, opt, sched, encoder_frozen=frozen)
+    got = checkpoint_manifest(checkpoint.load_checkpoint(tmp_path / "ft.pth"))
+    want = json.load(open(os.path.join(golden_dir, "finetune_checkpoint_manifest.json")))[tag]
+    keep = {"lr", "betas", "eps", "weight_decay", "initial_lr", "params"}
+    for side in (got, want):          # torch's AdamW carries implementation switches FusedAdamW has no use for
+        groups_ = side["dict"]["optimizer"]["dict"]["param_groups"]["list"]
+        for i, grp in enumerate(groups_):
+            groups_[i]["dict"] = {k: v for k, v in grp["dict"].items() if k in keep}
+    assert got == want

@@ -65,6 +65,15 @@ class FusedAdamW(torch.optim.Optimizer):
                 "exp_avg": self.exp_avg[o:o + n].view(p.shape),
                 "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape)}
 
+    def state_dict(self):
+        """torch.optim.AdamW's layout.  torch creates a parameter's state at its first step with a gradient, so a
+        parameter that has not been stepped yet (the predictor under the stage-1 objective, ft:196-232) has no entry:
+        the same here, although its slice of the flat buffers exists from the start."""
+        sd = super().state_dict()
+        never = {i for i, p in enumerate(self.params) if float(self.state[p]["step"]) == 0.0}
+        sd["state"] = {k: v for k, v in sd["state"].items() if k not in never}
+        return sd
+
     @torch.no_grad()
     def load_state_dict(self, state_dict) -> None:
         """Accepts what `state_dict()` of this class or of torch.optim.AdamW (same parameter order) wrote; the loaded

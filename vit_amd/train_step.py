@@ -34,6 +34,41 @@ class Stage1Heads(nn.Module):
                              if use_mask_aux else None)
 
 
+    def ordered(self):
+        """The heads in the order the reference's loops list them (s1:386-390, ft:205-210)."""
+        return [m for m in (self.temporal_classifier, self.contrastive_proj, self.denoise_head) if m is not None]
+
+
+def finetune_param_groups(model, heads: Stage1Heads, learning_rate: float = 4e-4, encoder_frozen: bool = True):
+    """The optimizer groups of the fine-tuning loop (stage1_vjepa2_finetuning.py:166-170, 196-232): one group per
+    sub-module in the reference's order -- the encoder first, at a tenth of the rate, when it trains; not at all (and
+    with `requires_grad` off, in eval mode as ft:263-264 puts it every epoch) when frozen.  Pass the result to
+    `FusedAdamW(groups, weight_decay=0.1, max_grad_norm=1.0)` or `torch.optim.AdamW(groups, weight_decay=0.1)`."""
+    groups = []
+    if encoder_frozen:
+        for p in model.encoder.parameters():
+            p.requires_grad = False
+        model.encoder.eval()
+    else:
+        groups.append({"params": list(model.encoder.parameters()), "lr": learning_rate * 0.1})
+    for part in (model.action_state_embed, model.video_proj, model.predictor_blocks, model.predictor_norm,
+                 model.predictor_to_encoder, model.sterility_classifier, model.autoregressive_predictor, *heads.ordered()):
+        groups.append({"params": list(part.parameters()), "lr": learning_rate})
+    return groups
+
+
+def warmup_cosine(warmup_epochs: int, num_epochs: int):
+    """The fine-tuning schedule's multiplier for `torch.optim.lr_scheduler.LambdaLR` (ft:235-241): linear warm-up
+    (epoch + 1) / warmup, then half a cosine over the remaining epochs."""
+    import math
+
+    def lr_lambda(epoch: int) -> float:
+        if epoch < warmup_epochs:
+            return (epoch + 1) / warmup_epochs
+        return 0.5 * (1 + math.cos(math.pi * (epoch - warmup_epochs) / (num_epochs - warmup_epochs)))
+    return lr_lambda
+
+
 class _TokenPool(torch.autograd.Function):
     """Mean over the token axis, (B, N, D) -> (B, D): one reduction kernel forward, one broadcast kernel backward."""
 
