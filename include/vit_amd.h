@@ -153,6 +153,25 @@ int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N, int64_t H, int64_t hd,
                 int64_t ldqkv, int64_t ldo, int64_t lddqkv, va_stream_t stream);
 
+/* Same with an explicit boolean mask (the `attn_mask` argument of RoPEMultiheadAttention.forward, swm:316-323: True =
+ * do not attend, any pattern; 2-D masks are shared by all batch entries and heads, 3-D ones by all heads).  The mask is
+ * handed over bit-packed, which va_attn_mask_pack does once per mask: `by_query` [batches, N, W] 32-bit words with
+ * W = 2 * ceil(N / 64) (va_attn_mask_words(N) = N * W words per [N, N] mask), bit j of word w of row q set <=> key
+ * 32 w + j is masked for query q (keys past N: set); `by_key` is the transpose (row = key, bits = queries), which the
+ * key-stationary backward pass reads.  stride_b / stride_h: words from one batch entry / head to the next, 0 when
+ * the mask is shared along that axis.  A query with every key masked gets NaN output, as in the reference (softmax of
+ * a row of -inf); its gradient contributions are then undefined.  No dropout variant (eval mode or p = 0). */
+int64_t va_attn_mask_words(int64_t N);
+int va_attn_mask_pack(const uint8_t* mask /* [batches, N, N] bytes, non-zero = masked */, int64_t batches, int64_t N,
+                      uint32_t* by_query, uint32_t* by_key, va_stream_t stream);
+int va_attn_fwd_masked(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N, int64_t H,
+                       int64_t hd, int64_t ldqkv, int64_t ldo, const uint32_t* mask_by_query, int64_t stride_b,
+                       int64_t stride_h, va_stream_t stream);
+int va_attn_bwd_masked(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse2,
+                       float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N, int64_t H, int64_t hd,
+                       int64_t ldqkv, int64_t ldo, int64_t lddqkv, const uint32_t* mask_by_query,
+                       const uint32_t* mask_by_key, int64_t stride_b, int64_t stride_h, va_stream_t stream);
+
 /* ---- training-mode dropout ---------------------------------------------------------------------------
  * The reference's encoder block applies nn.Dropout to the attention probabilities (swm:326, inside
  * scaled_dot_product_attention when the module is in training mode) and after both MLP linears (swm:700-702).

@@ -241,6 +241,96 @@ def test_attention_fwd_bwd(ops, dev, B, N, H):
         assert rel_err(dqkv[:, sl], leaf.grad[:, sl]) < 1.5e-2, name
 
 
+def _masks(kind, B, N, H, dev):
+    """Boolean masks (True = masked) in the shapes `masked_fill` broadcasts over (B, H, N, N); every query keeps at
+    least one key."""
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    i = torch.arange(N)
+    if kind == "random":            # 2-D, 60 % masked, diagonal kept
+        m = torch.rand(N, N, generator=gen) < 0.6
+        m[i, i] = False
+    elif kind == "future_only":     # a query sees itself and LATER keys: its first tiles are masked out entirely
+        m = i[None, :] < i[:, None]
+    elif kind == "causal7":         # block-causal, 7 tokens per timestep (N % 7 == 0 not needed here)
+        m = (i[None, :] // 7) > (i[:, None] // 7)
+    elif kind == "per_batch":       # 3-D
+        m = torch.rand(B, N, N, generator=gen) < 0.5
+        m[:, i, i] = False
+    elif kind == "per_head":        # 4-D, shared over the batch
+        m = torch.rand(1, H, N, N, generator=gen) < 0.5
+        m[:, :, i, i] = False
+    elif kind == "band":            # only a far-away band of keys is visible: whole leading AND trailing tiles masked
+        m = ~(((i[None, :] - i[:, None]) % N) // 8 == (N // 16))
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("B,N,H,kind", [(2, 8, 16, "random"), (1, 200, 16, "random"), (2, 300, 8, "per_batch"),
+                                        (2, 256, 16, "per_head"), (1, 1024, 16, "future_only"), (1, 1000, 8, "future_only"),
+                                        (2, 210, 16, "causal7"), (1, 2048, 16, "band"), (1, 2048, 8, "random")])
+def test_attention_with_explicit_mask_fwd_bwd(ops, dev, B, N, H, kind):
+    """`scores.masked_fill(attn_mask, -inf)` before the softmax (swm:316-323) against the fp32 formula, forward and
+    backward, for masks of every broadcast shape; same tolerances as the unmasked kernels."""
+    D = 1024
+    hd = D // H
+    qkv = rnd((B * N, 3 * D), dev, 21, dtype=BF16)
+    mask = _masks(kind, B, N, H, dev)
+    packed = ops.attn_mask_pack(mask, B, H)
+    out = torch.full((B * N, D), float("nan"), dtype=BF16, device=dev)
+    lse2 = torch.empty(B * H, N, dtype=F32, device=dev)
+    ops.attn_fwd(qkv, B, N, H, out, lse2, mask=packed)
+    leaf = qkv.float().requires_grad_(True)
+    q, k, v = (t.reshape(B, N, H, hd).permute(0, 2, 1, 3) for t in leaf.split(D, dim=1))
+    full = mask if mask.dim() == 4 else mask[:, None] if mask.dim() == 3 else mask[None, None]
+    s = ((q @ k.transpose(-1, -2)) * hd ** -0.5).masked_fill(full, float("-inf"))
+    ref_o = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * N, D)
+    ref_lse = (torch.logsumexp(s, dim=-1) * math.log2(math.e)).reshape(B * H, N)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out, ref_o) < 8e-3
+    assert (lse2 - ref_lse).abs().max().item() < 2e-2
+    d_out = rnd((B * N, D), dev, 22, dtype=BF16)
+    ref_o.backward(d_out.float())
+    dqkv = torch.full((B * N, 3 * D), float("nan"), dtype=BF16, device=dev)
+    ops.attn_bwd(qkv, out, d_out, lse2, dqkv, B, N, H, mask=packed)
+    assert torch.isfinite(dqkv.float()).all()
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert rel_err(dqkv[:, sl], leaf.grad[:, sl]) < 1.5e-2, name
+
+
+def test_attention_mask_packing_is_bit_exact(ops, dev):
+    """The packed words against a plain restatement: bit j of word w of row q = mask[q, 32 w + j], padding set; the
+    by-key words are the same of the transposed mask."""
+    N = 200
+    mask = torch.rand(2, N, N, generator=torch.Generator().manual_seed(9)) < 0.4
+    packed = ops.attn_mask_pack(mask.to(dev), 2, 16)
+    W = 2 * ((N + 63) // 64)
+    assert packed.stride_b == N * W and packed.stride_h == 0
+
+    def restate(m):
+        padded = torch.ones(2, N, W * 32, dtype=torch.bool)
+        padded[:, :, :N] = m
+        weights = (1 << torch.arange(32, dtype=torch.int64))
+        words = (padded.reshape(2, N, W, 32).long() * weights).sum(-1)
+        return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    assert torch.equal(packed.by_query.cpu().view(2, N, W), restate(mask))
+    assert torch.equal(packed.by_key.cpu().view(2, N, W), restate(mask.transpose(1, 2)))
+
+
+def test_attention_fully_masked_query_is_nan_like_the_reference(ops, dev):
+    """softmax over a row of -inf is NaN in the reference (swm:322-325); so is that query's output here, and the
+    other queries are untouched."""
+    B, N, H, D = 1, 128, 16, 1024
+    qkv = rnd((N, 3 * D), dev, 23, dtype=BF16)
+    mask = torch.zeros(N, N, dtype=torch.bool, device=dev)
+    mask[17, :] = True
+    out = torch.empty(N, D, dtype=BF16, device=dev)
+    lse2 = torch.empty(H, N, dtype=F32, device=dev)
+    ops.attn_fwd(qkv, B, N, H, out, lse2, mask=ops.attn_mask_pack(mask, B, H))
+    assert torch.isnan(out[17].float()).all()
+    ref_o, _ = attn_reference(qkv, B, N, H)
+    keep = torch.arange(N, device=dev) != 17
+    assert rel_err(out[keep], ref_o[keep]) < 8e-3
+
+
 def test_attention_online_softmax_rescale(ops, dev):
     """One key per tile spiked against one query forces the running-max rescale late in the sweep."""
     B, N, H, D = 1, 512, 16, 1024

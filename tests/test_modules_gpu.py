@@ -81,18 +81,57 @@ def test_attention_forward_backward_match_reference_golden(swm, golden_dir, head
         assert ((got - want).norm() / want.norm()).item() < 5e-2, nm       # 64 sampled entries
         np.testing.assert_allclose(flat.abs().sum().item(), g[f"{nm}_{tag}_digest"][1], rtol=2e-2)
 
-    # the reference's masked case (upper-triangular mask = block-causal with one token per timestep): forward only
+    # the reference's masked case (upper-triangular mask).  Without autograd it is recognised as block-causal with one
+    # token per timestep (the index-derived kernel); with autograd it goes through the packed-mask kernels, whose
+    # backward is checked against the reference's gradients
     tag = f"h{heads}_mask"
     xm = torch.from_numpy(g[f"x_{tag}"]).cuda()
     mask = torch.triu(torch.ones(8, 8, dtype=torch.bool, device="cuda"), diagonal=1)
     with torch.no_grad():
         ym = att(xm, rope_cache=cache, token_positions=pos, attn_mask=mask)
     assert rel(ym, torch.from_numpy(g[f"y_{tag}"])) < REL_TOL
+    att.zero_grad(set_to_none=True)
+    xm.requires_grad_(True)
+    ym2 = att(xm, rope_cache=cache, token_positions=pos, attn_mask=mask)
+    assert rel(ym2, torch.from_numpy(g[f"y_{tag}"])) < REL_TOL
+    (ym2 * torch.from_numpy(g[f"gy_{tag}"]).cuda()).sum().backward()
+    assert rel(xm.grad, torch.from_numpy(g[f"dx_{tag}"])) < REL_TOL
+    for nm, p in (("dwqkv", att.qkv_proj.weight), ("dwout", att.out_proj.weight)):
+        flat = p.grad.reshape(-1).double().cpu()
+        got, want = flat[torch.from_numpy(g[f"{nm}_{tag}_pos"])], torch.from_numpy(g[f"{nm}_{tag}_val"])
+        assert ((got - want).norm() / want.norm()).item() < 5e-2, nm
+        np.testing.assert_allclose(flat.abs().sum().item(), g[f"{nm}_{tag}_digest"][1], rtol=2e-2)
     from vit_amd._lib import VitAmdError
-    with pytest.raises(VitAmdError):            # no masked backward kernel: loud, not silently unmasked
-        att(xm.requires_grad_(True), rope_cache=cache, token_positions=pos, attn_mask=mask).sum().backward()
-    with pytest.raises(VitAmdError):            # arbitrary boolean masks have no kernel at all
+    with pytest.raises(VitAmdError):            # masked_fill needs a boolean mask (swm:322)
+        att(xm, attn_mask=torch.rand(8, 8, device="cuda"))
+    att.train()                                 # probabilities dropout + explicit mask: no kernel, said loudly
+    with pytest.raises(VitAmdError):
         att(xm, attn_mask=torch.rand(8, 8, device="cuda") < 0.3)
+    att.eval()
+
+
+def test_attention_with_an_arbitrary_mask_matches_the_formula(swm):
+    """A mask that is not block-causal, per batch entry (3-D), through the module: against the oracle's attention
+    (swm:283-336 restated in fp32) forward and backward."""
+    from oracle import ref_cpu as R
+    heads, B, N = 16, 2, 24
+    att = swm.RoPEMultiheadAttention(1024, heads, rope_dims={"t_dim": 256, "h_dim": 384, "w_dim": 384}).eval()
+    _fill(att, "blocks.0.attn.")
+    att = att.cuda()
+    cache, pos = _canonical(swm, (2, 3, 4), "cuda")
+    x = R.hashed_uniform("mod.attn.mask.x", (B, N, 1024), 1.0)
+    gy = R.hashed_uniform("mod.attn.mask.gy", (B, N, 1024), 1.0)
+    mask = torch.rand(B, N, N, generator=torch.Generator().manual_seed(4)) < 0.5
+    mask[:, torch.arange(N), torch.arange(N)] = False
+    xg = x.cuda().requires_grad_(True)
+    y = att(xg, rope_cache=cache, token_positions=pos, attn_mask=mask.cuda())
+    (y * gy.cuda()).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    ref = R.rope_attention(xr, att.qkv_proj.weight.detach().cpu(), att.out_proj.weight.detach().cpu(), heads, (2, 3, 4),
+                           attn_mask=mask)
+    (ref * gy).sum().backward()
+    assert rel(y, ref) < REL_TOL
+    assert rel(xg.grad, xr.grad) < REL_TOL
 
 
 def test_attention_without_rope_and_with_arbitrary_positions(swm):

@@ -43,6 +43,11 @@ SIGNATURES = {
     "va_attn_fwd_block_causal": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
     "va_attn_bwd_workspace_bytes": (i64, [i64, i64, i64]),
     "va_attn_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
+    "va_attn_mask_words": (i64, [i64]),
+    "va_attn_mask_pack": (ci, [vp, i64, i64, vp, vp, vp]),
+    "va_attn_fwd_masked": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, i64, i64, vp]),
+    "va_attn_bwd_masked": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, i64,
+                                vp]),
     "va_attn_fwd_dropout": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, cu32, cf, vp]),
     "va_attn_bwd_dropout": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, cu32, cf,
                                 vp]),

@@ -178,12 +178,26 @@ struct DropArgs {
 };
 VA_DEVINL uint32_t drop_half_stride(int N) { return ((uint32_t)N + 1u) >> 1; }   // NS / 2
 
+// Explicit boolean mask (swm:316-323, True = do not attend), bit-packed once per call: `by_q` [.., N, W] words with
+// W = 2 * ceil(N / 64), bit j of word w of row q set <=> key 32 w + j is masked for query q (keys >= N: set);
+// `by_k` the transpose (row = key, bit = query; queries >= N: set), which the key-stationary backward pass reads.
+// sb / sh: words from one batch entry / head to the next (0 = the mask is shared along that axis).
+struct MaskArgs {
+    const uint32_t* by_q;
+    const uint32_t* by_k;
+    int64_t sb, sh;
+};
+// In a 64-row tile a lane holds rows kb * 32 + acc32_row(i, h) = kb * 32 + 8 (i >> 2) + 4 h + (i & 3): with the tile's
+// two words shifted right by 4 h once, register i tests the compile-time bit 8 (i >> 2) + (i & 3).
+VA_DEVINL bool mask_bit(uint32_t shifted_word, int i) { return (shifted_word >> (8 * (i >> 2) + (i & 3))) & 1u; }
+
 template <int HD, int MODE, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE2, int N, int H, int64_t ld, int64_t ldo,
-                                                       float c, int tpt, DropArgs drop) {
+                                                       float c, int tpt, DropArgs drop, MaskArgs mask) {
     constexpr bool RAGGED = MODE != 0;
+    constexpr bool BITS = MODE == 3;
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
     constexpr int NBUF = fwd_ring_slots(HD), AHEAD = NBUF - 1, LOADS = 2 * TileSrc<HD>::PER_THREAD;
     constexpr float THR = 6.0f;
@@ -218,6 +232,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) negm[i] = 0.f;
     float m = 0.f, l = 0.f;
+    // BITS: the first tile need not hold a visible key, so "first tile" becomes "nothing seen yet", per query
+    bool seen = false;
+    const uint32_t* mrow = nullptr;
+    if (BITS) mrow = mask.by_q + b * mask.sb + hh * mask.sh + (int64_t)qrow_c * (2 * ((N + TILE_ROWS - 1) / TILE_ROWS));
 
     int klim = N;                                   // this lane's query sees keys [0, klim)
     int nt = (N + TILE_ROWS - 1) / TILE_ROWS;       // tiles the workgroup walks (uniform)
@@ -264,6 +282,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         VA_STAMP(0)
         const char* kt = smem + SLOT * 2 * TB;
         const char* vt = kt + TB;
+        u32x2_t mw = {0u, 0u};
+        if (BITS) mw = *(const u32x2_t*)(mrow + 2 * t);
 
         // hd 64: every LDS read of a phase is issued before its first MFMA (the fragments fit the register
         // file); hd 128: fragments are read next to their use.
@@ -293,7 +313,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                     for (int cb = 0; cb < CB; ++cb) vf[kb][s][cb] = tr_frag<HD>(vt, kb * 32 + 16 * s, cb, lane);
         }
         if (t + AHEAD < nt) stage(t + AHEAD, (SLOT + AHEAD) % NBUF);
-        if (MODE != 0 && __any((t + 1) * TILE_ROWS > klim)) {   // only builds with a key limit carry the selects
+        if (BITS) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint32_t w = mw[kb] >> (4 * h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (mask_bit(w, i)) st[kb][i] = -INFINITY;
+            }
+        } else if (MODE != 0 && __any((t + 1) * TILE_ROWS > klim)) {   // only builds with a key limit carry the selects
             const int rel = klim - t * TILE_ROWS;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -311,10 +339,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         float mx = max3(max3(mq[0], st[1][3], st[1][7]), max3(mq[1], st[1][11], st[1][15]), max3(mq[2], mq[3], mq[2]));
         mx = xhalf_max_fast(mx);
         VA_STAMP(1)
-        if (t == 0 || !__all(mx <= THR)) {
+        // BITS: a query that has seen no key yet takes its first visible tile's maximum (either sign); a tile that is
+        // masked out for it entirely (mx = -inf) moves nothing
+        const bool fresh = BITS ? !seen : t == 0;
+        const bool empty = BITS && mx == -INFINITY;
+        if (BITS ? !__all(fresh ? empty : mx <= THR) : (t == 0 || !__all(mx <= THR))) {
             // move the maximum: by the tile's own maximum on the first tile (either sign), upwards only later
-            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
-            const float alpha = t == 0 ? 1.f : fast_exp2(-delta);
+            const float delta = empty ? 0.f : fresh ? mx : fmaxf(mx, 0.f);
+            const float alpha = fresh ? 1.f : fast_exp2(-delta);
             m += delta;
             l *= alpha;
 #pragma unroll
@@ -328,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 st[1][i] -= delta;
             }
         }
+        if (BITS) seen = seen || !empty;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -394,7 +427,7 @@ VA_DEVINL void split3_bf16(float x, uint32_t& d0, uint32_t& d1) {
 // as -mul * delta (mul = 1, or 1 - p when the dropout rescale is folded into the output factors), written to
 // NEG_DELTA and, together with -lse2, as the 16-byte record the dK/dV pass feeds to the matrix pipe.
 // ------------------------------------------------------------------------------------------------
-template <int HD, bool RAGGED, bool DROP = false>
+template <int HD, bool RAGGED, bool DROP = false, bool BITS = false>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
                                                           const bf16_t* __restrict__ DO,
@@ -402,7 +435,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
                                                           float* __restrict__ NEG_DELTA, u32x4_t* __restrict__ AUX,
                                                           bf16_t* __restrict__ DQ, int N, int H, int64_t ld,
                                                           int64_t ldo, int64_t lddq, float c, float scale, float mul,
-                                                          DropArgs drop) {
+                                                          DropArgs drop, MaskArgs mask) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -467,6 +500,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
                                       (uint32_t)qrow_c * drop_half_stride(N) + 2u * (uint32_t)h);
     const uint32_t drop_thi = drop.thresh16 << 16;
     const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
+    const uint32_t* mrow = nullptr;
+    if (BITS) mrow = mask.by_q + b * mask.sb + hh * mask.sh + (int64_t)qrow_c * (2 * nt);
     TileSrc<HD> ts;
     ts.init(ld, tid);
     auto stage = [&](int tile, int slot) {
@@ -481,6 +516,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        u32x2_t mw = {0u, 0u};
+        if (BITS) mw = *(const u32x2_t*)(mrow + 2 * t);
         if (t + 1 < nt) stage(t + 1, SLOT ^ 1);
         const char* kt = smem + SLOT * 2 * TB;
         const char* vt = kt + TB;
@@ -504,12 +541,14 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
             for (int sidx = 0; sidx < 2; ++sidx)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) ktr[sidx][cb] = tr_frag<HD>(kt, kb * 32 + 16 * sidx, cb, lane);
-            const bool ragged = RAGGED && (t == nt - 1);
+            const bool ragged = RAGGED && !BITS && (t == nt - 1);      // BITS: keys past N are masked bits
+            const uint32_t mword = mw[kb] >> (4 * h);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float p = fast_exp2(s[i]);
                 if (ragged && t * TILE_ROWS + kb * 32 + acc32_row(i, h) >= N) p = 0.f;
-                s[i] = DROP ? p : p * dp[i];
+                if (BITS && mask_bit(mword, i)) p = 0.f;
+                s[i] = DROP ? p : (BITS && p == 0.f) ? 0.f : p * dp[i];
             }
             if (DROP) {      // dS / scale = P * (keep ? dO V^T - delta/scale : -delta/scale); DELTA holds delta/scale
                 const uint32_t wt = drop_w + (uint32_t)(t * (TILE_ROWS / 2) + kb * 16) * DROP_WEYL;
@@ -545,13 +584,14 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
 template <int HD, bool DROP>   // Q | dO | records | DROP: f32 -delta of the tile's queries
 constexpr int dkv_stage_bytes() { return 2 * TILE_ROWS * HD * 2 + TILE_ROWS * 16 + (DROP ? TILE_ROWS * 4 : 0); }
 
-template <int HD, bool RAGGED, bool DROP = false>
+template <int HD, bool RAGGED, bool DROP = false, bool BITS = false>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
                                                            const u32x4_t* __restrict__ AUX,
                                                            const float* __restrict__ NEG_DELTA, bf16_t* __restrict__ DK,
                                                            bf16_t* __restrict__ DV, int N, int H, int64_t ld,
-                                                           int64_t ldo, int64_t lddq, float c, float scale, DropArgs drop) {
+                                                           int64_t ldo, int64_t lddq, float c, float scale, DropArgs drop,
+                                                           MaskArgs mask) {
     constexpr int KS = HD / 16, CB = HD / 32, TB = TILE_ROWS * HD * 2;
     constexpr int STAGE = dkv_stage_bytes<HD, DROP>();
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE] | 16 zero bytes
@@ -593,6 +633,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
     const uint32_t drop_sh = (krow_c & 1) ? 0u : 16u;
     const uint32_t drop_thi = drop.thresh16 << 16;
     const int nt = (N + TILE_ROWS - 1) / TILE_ROWS;
+    const uint32_t* mrow = nullptr;      // this lane's key: which queries do not see it
+    if (BITS) mrow = mask.by_k + b * mask.sb + hh * mask.sh + (int64_t)krow_c * (2 * nt);
     TileSrc<HD> ts_q, ts_do;
     ts_q.init(ld, tid);
     ts_do.init(ldo, tid);
@@ -618,6 +660,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        u32x2_t mw = {0u, 0u};
+        if (BITS) mw = *(const u32x2_t*)(mrow + 2 * t);
         if (t + 1 < nt) stage(t + 1, SLOT ^ 1);
         const char* qt = smem + SLOT * STAGE;
         const char* dot = qt + TB;
@@ -651,7 +695,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
                     qtr[sidx][cb] = tr_frag<HD>(qt, qb * 32 + 16 * sidx, cb, lane);
                 }
             f32x16_t pr;
-            const bool ragged = RAGGED && (t == nt - 1);
+            const bool ragged = RAGGED && !BITS && (t == nt - 1);      // BITS: queries past N are masked bits
+            const uint32_t mword = mw[qb] >> (4 * h);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4_t nd;        // DROP: -delta of registers 4g..4g+3 (queries qb*32 + 8g + 4h + 0..3), what dP - delta
@@ -662,6 +707,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
                     const int i = 4 * g + j;
                     float p = fast_exp2(s[i]);
                     if (ragged && t * TILE_ROWS + qb * 32 + acc32_row(i, h) >= N) p = 0.f;
+                    if (BITS && mask_bit(mword, i)) p = 0.f;
                     if (DROP) {      // one word per element here: the pair partner (key ^ 1) lives in the neighbouring lane
                         const uint32_t qi = (uint32_t)(t * TILE_ROWS + qb * 32 + 8 * g + j);
                         const uint32_t hsh = drop_mix(drop_w + qi * drop_qstep);
@@ -670,7 +716,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
                         s[i] = p * (keep ? dp[i] : nd[j]);
                     } else {
                         pr[i] = p;
-                        s[i] = p * dp[i];
+                        s[i] = (BITS && p == 0.f) ? 0.f : p * dp[i];     // a fully masked query's dP - delta is NaN
                     }
                 }
                 // keep the four groups' hash chains apart: interleaved, their temporaries push the kernel into spills
@@ -723,21 +769,22 @@ int check_common(const char* who, int64_t B, int64_t N, int64_t H, int64_t hd, i
 
 template <int HD, int MODE, bool DROP>
 int fwd_launch_mode(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
-                    int64_t ld, int64_t ldo, int tpt, DropArgs drop, hipStream_t stream) {
+                    int64_t ld, int64_t ldo, int tpt, DropArgs drop, hipStream_t stream, MaskArgs mask = MaskArgs{}) {
     constexpr int LDS = fwd_ring_slots(HD) * 2 * TILE_ROWS * HD * 2;
     static bool flags[64] = {};
     const float c = 1.4426950408889634f / sqrtf((float)HD);
     const dim3 grid((N + 127) / 128, B * H);
     if (int e = set_lds(attn_fwd_kernel<HD, MODE, DROP>, LDS, flags, "va_attn_fwd")) return e;
     hipLaunchKernelGGL((attn_fwd_kernel<HD, MODE, DROP>), grid, dim3(256), LDS, stream, q, k, v, o, lse2, N, H, ld, ldo,
-                       c, tpt, drop);
+                       c, tpt, drop, mask);
     VA_CHECK_LAUNCH("va_attn_fwd");
     return VA_OK;
 }
 
 template <int HD>
 int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse2, int B, int N, int H,
-               int64_t ld, int64_t ldo, int tpt, DropArgs drop, hipStream_t stream) {
+               int64_t ld, int64_t ldo, int tpt, DropArgs drop, hipStream_t stream, MaskArgs mask = MaskArgs{}) {
+    if (mask.by_q) return fwd_launch_mode<HD, 3, false>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream, mask);
     if (drop.thresh16) {   // training-mode dropout: the encoder's attention only (no key limit other than N)
         if (N % TILE_ROWS) return fwd_launch_mode<HD, 1, true>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream);
         return fwd_launch_mode<HD, 0, true>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream);
@@ -747,18 +794,18 @@ int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, flo
     return fwd_launch_mode<HD, 0, false>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream);
 }
 
-template <int HD, bool RAGGED, bool DROP>
+template <int HD, bool RAGGED, bool DROP, bool BITS = false>
 int bwd_launch_as(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* d_o,
                   const float* lse2, float* workspace, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H,
-                  int64_t ld, int64_t ldo, int64_t lddq, DropArgs drop, hipStream_t stream) {
+                  int64_t ld, int64_t ldo, int64_t lddq, DropArgs drop, hipStream_t stream, MaskArgs mask = MaskArgs{}) {
     constexpr int LDS_DQ = 2 * 2 * TILE_ROWS * HD * 2;
     constexpr int LDS_DKV = 2 * dkv_stage_bytes<HD, DROP>() + 16;
     static bool f1[64] = {}, f2[64] = {};
-    if (int e = set_lds(attn_bwd_dq_kernel<HD, RAGGED, DROP>, LDS_DQ, f1, "va_attn_bwd")) return e;
+    if (int e = set_lds(attn_bwd_dq_kernel<HD, RAGGED, DROP, BITS>, LDS_DQ, f1, "va_attn_bwd")) return e;
     // With the mask code the whole-tile build of the dK/dV pass spills (its precomputed tile addresses stay live
     // across the hash temporaries); the build that clamps rows per tile does not and is correct for every N.
     constexpr bool RAGGED_DKV = RAGGED || DROP;
-    if (int e = set_lds(attn_bwd_dkv_kernel<HD, RAGGED_DKV, DROP>, LDS_DKV, f2, "va_attn_bwd")) return e;
+    if (int e = set_lds(attn_bwd_dkv_kernel<HD, RAGGED_DKV, DROP, BITS>, LDS_DKV, f2, "va_attn_bwd")) return e;
     const float scale = 1.0f / sqrtf((float)HD);
     const float c = 1.4426950408889634f * scale;
     const int64_t rows = (int64_t)B * N;
@@ -766,11 +813,11 @@ int bwd_launch_as(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_
     u32x4_t* aux = (u32x4_t*)workspace;
     float* delta = workspace + 4 * rows * H;
     const dim3 grid((N + 127) / 128, B * H);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, RAGGED, DROP>), grid, dim3(256), LDS_DQ, stream, q, k, v, o, d_o, lse2,
-                       delta, aux, dq, N, H, ld, ldo, lddq, c, scale, DROP ? 1.0f / drop.scale : 1.0f, drop);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, RAGGED, DROP, BITS>), grid, dim3(256), LDS_DQ, stream, q, k, v, o, d_o, lse2,
+                       delta, aux, dq, N, H, ld, ldo, lddq, c, scale, DROP ? 1.0f / drop.scale : 1.0f, drop, mask);
     VA_CHECK_LAUNCH("va_attn_bwd(dq)");
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, RAGGED_DKV, DROP>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux, delta,
-                       dk, dv, N, H, ld, ldo, lddq, c, scale, drop);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, RAGGED_DKV, DROP, BITS>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux, delta,
+                       dk, dv, N, H, ld, ldo, lddq, c, scale, drop, mask);
     VA_CHECK_LAUNCH("va_attn_bwd(dkv)");
     return VA_OK;
 }
@@ -778,7 +825,10 @@ int bwd_launch_as(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_
 template <int HD>
 int bwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* d_o,
                const float* lse2, float* workspace, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H, int64_t ld,
-               int64_t ldo, int64_t lddq, DropArgs drop, hipStream_t stream) {
+               int64_t ldo, int64_t lddq, DropArgs drop, hipStream_t stream, MaskArgs mask = MaskArgs{}) {
+    if (mask.by_q)
+        return bwd_launch_as<HD, true, false, true>(q, k, v, o, d_o, lse2, workspace, dq, dk, dv, B, N, H, ld, ldo, lddq, drop,
+                                                    stream, mask);
     const bool ragged = (N % TILE_ROWS) != 0;
 #define VA_BWD(R, D) bwd_launch_as<HD, R, D>(q, k, v, o, d_o, lse2, workspace, dq, dk, dv, B, N, H, ld, ldo, lddq, drop, stream)
     if (drop.thresh16) return ragged ? VA_BWD(true, true) : VA_BWD(false, true);
@@ -800,15 +850,15 @@ static int make_drop(const char* who, uint32_t key, float p, DropArgs* out) {
 
 static int attn_fwd_entry(const char* who, const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B,
                           int64_t N, int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t tpt, DropArgs drop,
-                          hipStream_t stream) {
+                          hipStream_t stream, MaskArgs mask = MaskArgs{}) {
     VA_CHECK_ARG(q && k && v && o && lse2, "%s: null operand", who);
     if (int e = check_common(who, B, N, H, hd, ldqkv, ldo)) return e;
     VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "%s: misaligned operand", who);
     if (hd == 64)
         return fwd_launch<64>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, (int)B, (int)N,
-                              (int)H, ldqkv, ldo, (int)tpt, drop, stream);
+                              (int)H, ldqkv, ldo, (int)tpt, drop, stream, mask);
     return fwd_launch<128>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, (int)B, (int)N, (int)H,
-                           ldqkv, ldo, (int)tpt, drop, stream);
+                           ldqkv, ldo, (int)tpt, drop, stream, mask);
 }
 
 extern "C" int va_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N,
@@ -841,7 +891,7 @@ extern "C" int64_t va_attn_bwd_workspace_bytes(int64_t B, int64_t N, int64_t H) 
 static int attn_bwd_entry(const char* who, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                           const float* lse2, float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N,
                           int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t lddqkv, DropArgs drop,
-                          hipStream_t stream) {
+                          hipStream_t stream, MaskArgs mask = MaskArgs{}) {
     VA_CHECK_ARG(q && k && v && o && d_o && lse2 && workspace && dq && dk && dv, "%s: null operand", who);
     VA_CHECK_ARG((uintptr_t)workspace % 16 == 0, "%s: workspace must be 16-byte aligned", who);
     if (int e = check_common(who, B, N, H, hd, ldqkv, ldo)) return e;
@@ -852,10 +902,10 @@ static int attn_bwd_entry(const char* who, const void* q, const void* k, const v
     if (hd == 64)
         return bwd_launch<64>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
                               lse2, workspace, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo,
-                              lddqkv, drop, stream);
+                              lddqkv, drop, stream, mask);
     return bwd_launch<128>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
                            lse2, workspace, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo, lddqkv,
-                           drop, stream);
+                           drop, stream, mask);
 }
 
 extern "C" int va_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
@@ -873,4 +923,83 @@ extern "C" int va_attn_bwd_dropout(const void* q, const void* k, const void* v, 
     if (int e = make_drop("va_attn_bwd_dropout", key, p, &drop)) return e;
     return attn_bwd_entry("va_attn_bwd_dropout", q, k, v, o, d_o, lse2, workspace, dq, dk, dv, B, N, H, hd, ldqkv, ldo,
                           lddqkv, drop, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Explicit boolean masks.  One thread per output word: `by_q` word (r, w) collects mask[r][32 w .. 32 w + 31] (32
+// contiguous bytes), `by_k` word (c, w) collects mask[32 w .. 32 w + 31][c] (a column: neighbouring threads read
+// neighbouring bytes).  Positions past N read as masked.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_mask_pack_kernel(const uint8_t* __restrict__ mask, int64_t batches, int N, int W,
+                                                             uint32_t* __restrict__ by_q, uint32_t* __restrict__ by_k) {
+    const int64_t per = (int64_t)N * W;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= batches * per) return;
+    const int64_t bi = id / per;
+    const int64_t rem = id - bi * per;
+    const uint8_t* mb = mask + bi * (int64_t)N * N;
+    {   // rem = r * W + w
+        const int r = (int)(rem / W), w = (int)(rem - (int64_t)r * W);
+        uint32_t bits = 0;
+        for (int j = 0; j < 32; ++j) {
+            const int c = 32 * w + j;
+            bits |= (c >= N || mb[(int64_t)r * N + c] != 0) ? (1u << j) : 0u;
+        }
+        by_q[id] = bits;
+    }
+    {   // rem = w * N + c (column fastest across threads); stored at (c, w)
+        const int w = (int)(rem / N), c = (int)(rem - (int64_t)w * N);
+        uint32_t bits = 0;
+        for (int j = 0; j < 32; ++j) {
+            const int r = 32 * w + j;
+            bits |= (r >= N || mb[(int64_t)r * N + c] != 0) ? (1u << j) : 0u;
+        }
+        by_k[bi * per + (int64_t)c * W + w] = bits;
+    }
+}
+
+extern "C" int64_t va_attn_mask_words(int64_t N) { return N > 0 ? N * 2 * ((N + TILE_ROWS - 1) / TILE_ROWS) : 0; }
+
+extern "C" int va_attn_mask_pack(const uint8_t* mask, int64_t batches, int64_t N, uint32_t* by_query, uint32_t* by_key,
+                                 hipStream_t stream) {
+    VA_CHECK_ARG(mask && by_query && by_key, "va_attn_mask_pack: null operand");
+    VA_CHECK_ARG(batches > 0 && N > 0 && N < (1 << 24), "va_attn_mask_pack: bad shape");
+    VA_CHECK_ARG(((uintptr_t)by_query | (uintptr_t)by_key) % 8 == 0, "va_attn_mask_pack: outputs must be 8-byte aligned");
+    const int W = 2 * (int)((N + TILE_ROWS - 1) / TILE_ROWS);
+    const int64_t total = batches * N * W;
+    VA_CHECK_ARG((total + 255) / 256 < (1ll << 31), "va_attn_mask_pack: too many mask words");
+    hipLaunchKernelGGL(attn_mask_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, mask, batches, (int)N, W,
+                       by_query, by_key);
+    VA_CHECK_LAUNCH("va_attn_mask_pack");
+    return VA_OK;
+}
+
+static int make_mask(const char* who, const uint32_t* by_query, const uint32_t* by_key, bool need_by_key, int64_t stride_b,
+                     int64_t stride_h, MaskArgs* out) {
+    VA_CHECK_ARG(by_query && (by_key || !need_by_key), "%s: null mask", who);
+    VA_CHECK_ARG(stride_b >= 0 && stride_h >= 0 && stride_b % 2 == 0 && stride_h % 2 == 0,
+                 "%s: mask strides must be even and non-negative", who);
+    VA_CHECK_ARG(((uintptr_t)by_query | (uintptr_t)by_key) % 8 == 0, "%s: mask words must be 8-byte aligned", who);
+    *out = MaskArgs{by_query, by_key, stride_b, stride_h};
+    return VA_OK;
+}
+
+extern "C" int va_attn_fwd_masked(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N,
+                                  int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, const uint32_t* mask_by_query,
+                                  int64_t stride_b, int64_t stride_h, hipStream_t stream) {
+    MaskArgs mask;
+    if (int e = make_mask("va_attn_fwd_masked", mask_by_query, nullptr, false, stride_b, stride_h, &mask)) return e;
+    return attn_fwd_entry("va_attn_fwd_masked", q, k, v, o, lse2, B, N, H, hd, ldqkv, ldo, 0, DropArgs{0u, 0u, 1.f}, stream,
+                          mask);
+}
+
+extern "C" int va_attn_bwd_masked(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                  const float* lse2, float* workspace, void* dq, void* dk, void* dv, int64_t B, int64_t N,
+                                  int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo, int64_t lddqkv,
+                                  const uint32_t* mask_by_query, const uint32_t* mask_by_key, int64_t stride_b,
+                                  int64_t stride_h, hipStream_t stream) {
+    MaskArgs mask;
+    if (int e = make_mask("va_attn_bwd_masked", mask_by_query, mask_by_key, true, stride_b, stride_h, &mask)) return e;
+    return attn_bwd_entry("va_attn_bwd_masked", q, k, v, o, d_o, lse2, workspace, dq, dk, dv, B, N, H, hd, ldqkv, ldo, lddqkv,
+                          DropArgs{0u, 0u, 1.f}, stream, mask);
 }

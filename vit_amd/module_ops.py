@@ -109,6 +109,7 @@ class AttnSpec:
     key: str                           # name prefix of its entries
     rope: Optional[Tuple] = None       # (tables ((cos,sin) x 3), pos int32 [3, N]) or None
     tokens_per_timestep: int = 0       # > 0: block-causal mask (forward only)
+    mask: object = None                # ops.PackedMask: an explicit boolean mask (forward and backward, no dropout)
     drop_key: int = 0
     drop_p: float = 0.0
 
@@ -128,7 +129,7 @@ class RopeAttentionFn(torch.autograd.Function):
         attn = torch.empty(B * N, D, dtype=BF16, device=h.device)
         lse2 = torch.empty(B * H, N, dtype=F32, device=h.device)
         ops.attn_fwd(qkv, B, N, H, attn, lse2, tokens_per_timestep=spec.tokens_per_timestep,
-                     drop_key=spec.drop_key, drop_p=spec.drop_p)
+                     drop_key=spec.drop_key, drop_p=spec.drop_p, mask=spec.mask)
         out = torch.empty(B * N, D, dtype=F32, device=h.device)
         r2 = None if resid is None else resid.detach().to(F32).contiguous().view(B * N, D)
         ops.gemm_nt(attn, spec.cache.fwd(spec.key + "out", wout), ops.EPI_F32, out, resid=r2)
@@ -151,7 +152,7 @@ class RopeAttentionFn(torch.autograd.Function):
         dwout = torch.zeros(D, D, dtype=F32, device=g.device)
         ops.gemm_tn_accum(g_bf, attn, dwout)
         dqkv = torch.empty(M, 3 * D, dtype=BF16, device=g.device)
-        ops.attn_bwd(qkv, attn, d_o, lse2, dqkv, B, N, H, drop_key=spec.drop_key, drop_p=spec.drop_p)
+        ops.attn_bwd(qkv, attn, d_o, lse2, dqkv, B, N, H, drop_key=spec.drop_key, drop_p=spec.drop_p, mask=spec.mask)
         if spec.rope is not None:
             ops.rope3d_qk_indexed_(dqkv, spec.rope[0], spec.rope[1], N, transpose=True)
         dh = None

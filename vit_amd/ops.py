@@ -269,11 +269,41 @@ def rope3d_qk_indexed_(qkv: torch.Tensor, cache, pos: torch.Tensor, n_tokens: in
 
 
 # ------------------------------------------------------------------ attention
+class PackedMask:
+    """An explicit boolean attention mask (True = do not attend, swm:316-323) in the bit-packed form the kernels read:
+    `by_query` / `by_key` int32 [batches, heads, N, W] with stride_b / stride_h = 0 where the mask is shared."""
+
+    def __init__(self, by_query, by_key, stride_b: int, stride_h: int, n: int):
+        self.by_query, self.by_key, self.stride_b, self.stride_h, self.n = by_query, by_key, stride_b, stride_h, n
+
+
+def attn_mask_pack(mask: torch.Tensor, B: int, H: int) -> PackedMask:
+    """mask: bool [N, N], [B, N, N], or 4-D [B or 1, H or 1, N, N] (what `scores.masked_fill(attn_mask, -inf)` takes
+    after the reference's unsqueezing), on the device.  One kernel packs it by query and by key."""
+    if mask.dtype != torch.bool or not mask.is_cuda:
+        raise ValueError("attn_mask_pack: a boolean device tensor is required")
+    if mask.dim() == 2:
+        mask = mask[None, None]
+    elif mask.dim() == 3:
+        mask = mask[:, None]
+    if mask.dim() != 4 or mask.shape[-1] != mask.shape[-2] or mask.shape[0] not in (1, B) or mask.shape[1] not in (1, H):
+        raise ValueError(f"attn_mask_pack: mask of shape {tuple(mask.shape)} does not broadcast to ({B}, {H}, N, N)")
+    mb, mh, N = mask.shape[0], mask.shape[1], mask.shape[-1]
+    lib = _lib.load()
+    words = int(lib.va_attn_mask_words(N))
+    bytes_ = mask.contiguous().view(torch.uint8)
+    by_q = torch.empty(mb * mh * words, dtype=torch.int32, device=mask.device)
+    by_k = torch.empty_like(by_q)
+    check(lib.va_attn_mask_pack(_p(bytes_), mb * mh, N, _p(by_q), _p(by_k), _stream()), "va_attn_mask_pack")
+    return PackedMask(by_q, by_k, mh * words if mb > 1 else 0, words if mh > 1 else 0, N)
+
+
 def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2: torch.Tensor,
-             tokens_per_timestep: int = 0, drop_key: int = 0, drop_p: float = 0.0):
+             tokens_per_timestep: int = 0, drop_key: int = 0, drop_p: float = 0.0, mask: Optional[PackedMask] = None):
     """qkv: packed [B*N, 3*D] bf16 (q | k | v thirds); out [B*N, D] bf16; lse2 [B*H, N] f32.
     tokens_per_timestep > 0 selects the predictor's block-causal mask (forward only).
-    drop_p > 0: training-mode dropout on the attention probabilities, masks derived from drop_key."""
+    drop_p > 0: training-mode dropout on the attention probabilities, masks derived from drop_key.
+    mask: an explicit boolean mask packed by `attn_mask_pack` (no dropout with it)."""
     _need(qkv, BF16, "qkv"); _need(out, BF16, "out"); _need(lse2, F32, "lse2")
     M, W3 = qkv.shape
     D = W3 // 3
@@ -282,7 +312,12 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2:
     hd = D // H
     es = qkv.element_size()
     ptrs = (qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out), _p(lse2))
-    if tokens_per_timestep > 0:
+    if mask is not None:
+        if drop_p > 0 or tokens_per_timestep > 0 or mask.n != N:
+            raise ValueError("attn_fwd: an explicit mask excludes dropout and the block-causal mode, and must be N x N")
+        check(_lib.load().va_attn_fwd_masked(*ptrs, B, N, H, hd, _ld(qkv), _ld(out), _p(mask.by_query), mask.stride_b,
+                                             mask.stride_h, _stream()), "va_attn_fwd_masked")
+    elif tokens_per_timestep > 0:
         if drop_p > 0:
             raise ValueError("attn_fwd: dropout is not available with the block-causal mask")
         check(_lib.load().va_attn_fwd_block_causal(*ptrs, B, N, H, hd, _ld(qkv), _ld(out), tokens_per_timestep,
@@ -295,8 +330,9 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, out: torch.Tensor, lse2:
     return out
 
 
-def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int, drop_key: int = 0, drop_p: float = 0.0):
-    """drop_key / drop_p: the values the forward ran with (the masks are regenerated, not stored)."""
+def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int, drop_key: int = 0, drop_p: float = 0.0,
+             mask: Optional[PackedMask] = None):
+    """drop_key / drop_p: the values the forward ran with (the masks are regenerated, not stored); mask: the forward's."""
     _need(qkv, BF16, "qkv"); _need(out, BF16, "out"); _need(d_out, BF16, "d_out"); _need(dqkv, BF16, "dqkv")
     M, W3 = qkv.shape
     D = W3 // 3
@@ -309,7 +345,12 @@ def attn_bwd(qkv, out, d_out, lse2, dqkv, B: int, N: int, H: int, drop_key: int 
     args = (qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es, _p(out), _p(d_out), _p(lse2),
             _p(delta), dqkv.data_ptr(), dqkv.data_ptr() + D * es, dqkv.data_ptr() + 2 * D * es, B, N, H, hd, _ld(qkv),
             _ld(out), _ld(dqkv))
-    if drop_p > 0:
+    if mask is not None:
+        if drop_p > 0 or mask.n != N:
+            raise ValueError("attn_bwd: an explicit mask excludes dropout and must be N x N")
+        check(lib.va_attn_bwd_masked(*args, _p(mask.by_query), _p(mask.by_key), mask.stride_b, mask.stride_h, _stream()),
+              "va_attn_bwd_masked")
+    elif drop_p > 0:
         check(lib.va_attn_bwd_dropout(*args, drop_key & 0xffffffff, float(drop_p), _stream()), "va_attn_bwd_dropout")
     else:
         check(lib.va_attn_bwd(*args, _stream()), "va_attn_bwd")

@@ -184,32 +184,48 @@ class RoPEMultiheadAttention(nn.Module):
         return tables, pos
 
     @staticmethod
-    def _mask_period(attn_mask, L: int) -> int:
-        """0 for no mask, tokens-per-timestep for a block-causal mask (BlockCausalMask.create_mask); any other
-        boolean mask has no kernel."""
-        if attn_mask is None:
-            return 0
+    def _block_causal_period(attn_mask, L: int) -> int:
+        """tokens-per-timestep if `attn_mask` is a block-causal mask (BlockCausalMask.create_mask), else 0."""
         tpt = getattr(attn_mask, "tokens_per_timestep", None)
         if tpt is None and attn_mask.dim() == 2 and tuple(attn_mask.shape) == (L, L) and attn_mask.dtype == torch.bool:
             cand = int((~attn_mask[0]).sum())
             if cand > 0 and L % cand == 0 and torch.equal(attn_mask, BlockCausalMask.create_mask(L, cand, attn_mask.device)):
                 tpt = cand
-        if not tpt or L % tpt:
-            raise VitAmdError("only block-causal boolean masks (every token sees its own and earlier timesteps) have an "
-                              "attention kernel; the encoder itself never passes a mask (swm:813)")
-        return int(tpt)
+        return int(tpt) if tpt and L % tpt == 0 else 0
+
+    def _mask_operands(self, attn_mask, B: int, L: int, needs_grad: bool, p: float):
+        """(tokens_per_timestep, packed mask) for the kernels (swm:316-323, True = masked).  A block-causal mask takes
+        the kernel that derives it from the token index when no gradient is wanted (that kernel is forward-only); every
+        other boolean mask -- 2-D, 3-D (per batch entry) or 4-D -- and a block-causal one under autograd is bit-packed."""
+        if attn_mask is None:
+            return 0, None
+        if attn_mask.dtype != torch.bool:
+            raise VitAmdError("attn_mask must be boolean (True = do not attend), as `masked_fill` requires (swm:322)")
+        if not needs_grad:
+            tpt = self._block_causal_period(attn_mask, L)
+            if tpt:
+                return tpt, None
+        if p > 0:
+            raise VitAmdError("no kernel combines an explicit attention mask with training-mode dropout on the "
+                              "probabilities; call .eval() or build the module with dropout=0")
+        if tuple(attn_mask.shape[-2:]) != (L, L):
+            raise VitAmdError(f"attn_mask of shape {tuple(attn_mask.shape)} does not fit {L} tokens")
+        return 0, ops.attn_mask_pack(attn_mask.to(self.qkv_proj.weight.device), B, self.num_heads)
 
     def forward(self, x, rope_cache=None, token_positions=None, attn_mask=None, _resid=None):
         """swm:283-336 on the kernels: QKV GEMM, rotation of the full-width Q and K, flash attention, output GEMM.
-        `attn_mask` (True = masked) may be None or a block-causal mask; the latter is forward-only."""
+        `attn_mask` (True = masked): None, or any boolean mask `masked_fill` would broadcast over (B, heads, N, N)."""
         _need_device(x, "RoPEMultiheadAttention.forward")
         B, N, C = x.shape
         if C != self.embed_dim or self.head_dim not in (64, 128) or C % 128:
             raise VitAmdError(f"no attention kernel for embed_dim {C} with head_dim {self.head_dim} (64 or 128 needed)")
         p = self.dropout.p if self.dropout.training else 0.0
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.qkv_proj.weight.requires_grad or
+                                                  self.out_proj.weight.requires_grad)
+        tpt, packed = self._mask_operands(attn_mask, B, N, needs_grad, p)
         spec = module_ops.AttnSpec(heads=self.num_heads, cache=_own_cache(self), key="",
                                    rope=self._rope_operands(rope_cache, token_positions, N, x.device),
-                                   tokens_per_timestep=self._mask_period(attn_mask, N),
+                                   tokens_per_timestep=tpt, mask=packed,
                                    drop_key=_draw_key() if p > 0 else 0, drop_p=p)
         return module_ops.RopeAttentionFn.apply(x, self.qkv_proj.weight, self.out_proj.weight, _resid, spec)
 
