@@ -33,6 +33,8 @@ typedef struct ihipStream_t* va_stream_t; /* == hipStream_t */
 #define VA_EPI_BIAS_GELU 1 /* out(bf16) = acc + bias ; out2(bf16) = gelu_erf(acc + bias)  */
 #define VA_EPI_F32 2       /* out(f32)  = acc [+ bias] [+ resid(f32)]                     */
 #define VA_EPI_GELU_BWD 3  /* out(bf16) = acc * gelu_erf'(aux(bf16))                      */
+#define VA_EPI_GELU_ONLY 4 /* out(bf16) = gelu_erf(acc + bias): the forward of a pass that keeps nothing for a
+                              backward (half the output bytes of VA_EPI_BIAS_GELU) */
 
 int va_version(void);
 const char* va_last_error(void);
@@ -50,6 +52,7 @@ int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, int64_t K, in
 /* The same with a training-mode dropout (nn.Dropout of swm:700, 702 and its backward) folded into the epilogue,
  * with the decisions va_dropout(key, p) makes over the contiguous [M,N] output (ldc == N, M*N < 2^32):
  *   VA_EPI_BIAS_GELU: out2 = drop(gelu(acc + bias));  VA_EPI_F32: out = drop(acc + bias) + resid;
+ *   VA_EPI_GELU_ONLY: out = drop(gelu(acc + bias));
  *   VA_EPI_GELU_BWD:  out = drop(acc * gelu'(aux)).   p == 0 is va_gemm_nt.  Not with tile >= 4256. */
 int va_gemm_nt_dropout(const void* x, const void* w, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
                        int epilogue, void* out, void* out2, const float* bias, const float* resid, const void* aux,

@@ -136,6 +136,10 @@ def test_gemm_nt_epilogues(ops, dev, tile, M):
     ops.gemm_nt(x, w, ops.EPI_BIAS_GELU, pre, out2=act, bias=bias, tile=tile)
     assert rel_err(pre, acc + bias) < 4e-3
     assert rel_err(act, torch.nn.functional.gelu(acc + bias)) < 5e-3
+    # the same without the pre-activation output (no-grad passes): the activation must be the very same bits
+    act_only = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_GELU_ONLY, act_only, bias=bias, tile=tile)
+    assert torch.equal(act_only, act)
     # GELU backward epilogue
     g = torch.empty(M, N, dtype=BF16, device=dev)
     ops.gemm_nt(x, w, ops.EPI_GELU_BWD, g, aux=pre, tile=tile)

@@ -86,6 +86,11 @@ VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M
                 if (ep.drop_thi) drop_run<4>(gl, (uint32_t)o, ep);
                 u32x2_t gk = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3])};
                 *(u32x2_t*)((bf16_t*)ep.out2 + o) = gk;
+            } else if (EPI == VA_EPI_GELU_ONLY) {
+                float gl[4] = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+                if (ep.drop_thi) drop_run<4>(gl, (uint32_t)o, ep);
+                u32x2_t gk = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3])};
+                *(u32x2_t*)((bf16_t*)ep.out + o) = gk;
             } else if (EPI == VA_EPI_F32) {
                 if (ep.drop_thi) drop_run<4>(v, (uint32_t)o, ep);
                 if (ep.resid != nullptr) {
@@ -185,6 +190,18 @@ VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, i
             u32x4_t ghi = {pack_bf16x2(gl[8], gl[9]), pack_bf16x2(gl[10], gl[11]), pack_bf16x2(gl[12], gl[13]), pack_bf16x2(gl[14], gl[15])};
             *(u32x4_t*)((bf16_t*)ep.out2 + o_lo) = glo;
             *(u32x4_t*)((bf16_t*)ep.out2 + o_hi) = ghi;
+        } else if (EPI == VA_EPI_GELU_ONLY) {
+            float gl[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gl[j] = gelu_erf(v[j]);
+            if (CAN_DROP && ep.drop_thi) {
+                drop_run<8>(gl, (uint32_t)o_lo, ep);
+                drop_run<8>(gl + 8, (uint32_t)o_hi, ep);
+            }
+            u32x4_t glo = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3]), pack_bf16x2(gl[4], gl[5]), pack_bf16x2(gl[6], gl[7])};
+            u32x4_t ghi = {pack_bf16x2(gl[8], gl[9]), pack_bf16x2(gl[10], gl[11]), pack_bf16x2(gl[12], gl[13]), pack_bf16x2(gl[14], gl[15])};
+            *(u32x4_t*)((bf16_t*)ep.out + o_lo) = glo;
+            *(u32x4_t*)((bf16_t*)ep.out + o_hi) = ghi;
         } else if (EPI == VA_EPI_F32) {
             if (CAN_DROP && ep.drop_thi) {
 #pragma unroll
@@ -702,7 +719,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     // loads a stage needs are followed by two stages' loads AND those stores (32 instructions per wave for one
     // 2-byte output, 64 otherwise): that many may stay in flight, and the stores need not drain before the matrix
     // work resumes.  (An edge tile skips the stores of missing row blocks, so it gets the plain count.)
-    constexpr int STORES = (EPI == VA_EPI_BF16 || EPI == VA_EPI_GELU_BWD) ? 32 : 64;
+    constexpr int STORES = (EPI == VA_EPI_BF16 || EPI == VA_EPI_GELU_BWD || EPI == VA_EPI_GELU_ONLY) ? 32 : 64;
     constexpr int RELAXED = 2 * LPS + STORES < 63 ? 2 * LPS + STORES : 63;
     auto sync = [&](bool relaxed) {
         if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_body += now - t_last; t_last = now; }
@@ -933,6 +950,9 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
         case VA_EPI_BIAS_GELU:
             VA_CHECK_ARG(out2 && bias, "va_gemm_nt: bias+GELU epilogue needs out2 and bias");
             return launch_epi<VA_EPI_BIAS_GELU>(tile, X, W, (int)M, (int)N, (int)K, (int)ldx, (int)ldw, ep, stream);
+        case VA_EPI_GELU_ONLY:
+            VA_CHECK_ARG(bias, "va_gemm_nt: the GELU epilogue needs a bias");
+            return launch_epi<VA_EPI_GELU_ONLY>(tile, X, W, (int)M, (int)N, (int)K, (int)ldx, (int)ldw, ep, stream);
         case VA_EPI_F32:
             return launch_epi<VA_EPI_F32>(tile, X, W, (int)M, (int)N, (int)K, (int)ldx, (int)ldw, ep, stream);
         case VA_EPI_GELU_BWD:

@@ -284,10 +284,16 @@ class EncoderEngine:
             mean2, rstd2 = stat("mean2"), stat("rstd2")
             ln2 = buf("ln2", D, BF16)
             ops.layernorm_fwd(x_mid, P[p + "norm2.weight"], P[p + "norm2.bias"], ln2, mean2, rstd2, LN_EPS)
-            pre, act = buf("pre", 4 * D, BF16), buf("act", 4 * D, BF16)
+            act = buf("act", 4 * D, BF16)
             # both MLP dropouts ride in the GEMM epilogues; the saved activation is the dropped one
-            ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BIAS_GELU, pre, out2=act,
-                        bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
+            if save:
+                pre = new(4 * D, BF16)
+                ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BIAS_GELU, pre, out2=act,
+                            bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
+            else:       # nothing is kept for a backward: the pre-activation (half of this GEMM's output bytes) is not written
+                pre = None
+                ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_GELU_ONLY, act,
+                            bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
             x_next = buf("x_out", D, F32) if save else buf("x_out" + str(i & 1), D, F32)
             ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next,
                         bias=P[p + "mlp.3.bias"], resid=x_mid, drop_key=k2, drop_p=p2)

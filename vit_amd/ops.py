@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import check
 
-EPI_BF16, EPI_BIAS_GELU, EPI_F32, EPI_GELU_BWD = 0, 1, 2, 3
+EPI_BF16, EPI_BIAS_GELU, EPI_F32, EPI_GELU_BWD, EPI_GELU_ONLY = 0, 1, 2, 3, 4
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -42,7 +42,7 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, epilogue: int, out: torch.Tensor, 
             bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
             aux: Optional[torch.Tensor] = None, tile: int = 0, drop_key: int = 0, drop_p: float = 0.0) -> torch.Tensor:
     """out[M,N] = x[M,K] @ w[N,K]^T with a fused epilogue (see include/vit_amd.h).  drop_p > 0 applies the dropout
-    of `dropout(…, drop_key, drop_p)` inside the epilogue: to the GELU output (EPI_BIAS_GELU), to acc + bias before
+    of `dropout(…, drop_key, drop_p)` inside the epilogue: to the GELU output (EPI_BIAS_GELU, EPI_GELU_ONLY), to acc + bias before
     the residual (EPI_F32), to the product with the GELU derivative (EPI_GELU_BWD)."""
     _need(x, BF16, "x"); _need(w, BF16, "w")
     M, K = x.shape

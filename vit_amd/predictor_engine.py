@@ -83,9 +83,8 @@ def block_forward(blk, x: torch.Tensor, tokens_per_timestep: int, state: Optiona
         x_mid = x_dn
 
     ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, ln, mean, rstd, blk.norm2.eps)
-    pre, act = new(4 * D, BF16), new(4 * D, BF16)
-    ops.gemm_nt(ln, wc.fwd("fc1", blk.mlp[0].weight), ops.EPI_BIAS_GELU, pre, out2=act, bias=blk.mlp[0].bias.detach())
-    del pre
+    act = new(4 * D, BF16)
+    ops.gemm_nt(ln, wc.fwd("fc1", blk.mlp[0].weight), ops.EPI_GELU_ONLY, act, bias=blk.mlp[0].bias.detach())
     x_out = new(D, F32)
     ops.gemm_nt(act, wc.fwd("fc2", blk.mlp[2].weight), ops.EPI_F32, x_out, bias=blk.mlp[2].bias.detach(), resid=x_mid)
     return x_out.view(B, L, D), new_state
