@@ -167,6 +167,58 @@ def test_deterministic_mode_gives_bit_identical_gradients(swm):
         assert rel(a[k], base[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("train_mode_dropout", [False, True])
+def test_activation_checkpointing_recomputes_the_same_gradients(swm, train_mode_dropout):
+    """use_grad_checkpoint (swm:807-811, active in training mode): only the blocks' inputs are kept and the backward
+    runs each block's forward again.  Output and -- in deterministic mode -- every gradient are bit-identical to the
+    run that keeps all activations, with the training-mode dropout masks too (they are functions of their keys); the
+    peak memory of the step is lower; the flag does nothing in eval mode; policy "auto" keeps everything when it fits."""
+    from vit_amd import ops
+    enc = swm.VideoViTEncoder(img_size=128, num_frames=8, embed_dim=1024, depth=4, num_heads=16, use_grad_checkpoint=True)
+    enc.load_state_dict(R.fill_state_dict_(enc.state_dict()))
+    enc = enc.cuda().train()
+    if not train_mode_dropout:
+        for m in enc.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    video = R.hashed_uniform("test.video.ckpt", (8, 3, 8, 128, 128), 1.0).cuda().requires_grad_(True)   # 2048 tokens
+
+    def run(policy, keep_results=True):
+        enc.checkpoint_policy = policy
+        enc.zero_grad(set_to_none=True)
+        video.grad = None
+        torch.manual_seed(77)                       # the dropout keys are drawn from torch's CPU generator
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        y = enc(video)
+        (y ** 2).mean().backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated()
+        if not keep_results:
+            return peak
+        return y.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters()}, video.grad.clone()
+
+    assert not enc._checkpointing(video.detach()) or enc.checkpoint_policy != "auto"      # tiny problem: fits
+    ops.set_deterministic(True)
+    try:
+        run("never", keep_results=False)            # warm-up: operand copies of the weights, allocator pools
+        peak0 = run("never", keep_results=False)
+        peak1 = run("always", keep_results=False)
+        y0, g0, dv0 = run("never")
+        y1, g1, dv1 = run("always")
+        y2, g2, dv2 = run("auto")
+    finally:
+        ops.set_deterministic(False)
+    assert torch.equal(y0, y1) and torch.equal(dv0, dv1) and torch.equal(y0, y2)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+        assert torch.equal(g0[k], g2[k]), k
+    assert peak1 < peak0, (peak1, peak0)
+    enc.eval()
+    enc.checkpoint_policy = "always"
+    assert not enc._checkpointing(video.detach())   # eval mode: the reference does not checkpoint either (swm:808)
+
+
 def test_refresh_weights_after_a_write_through_data(swm):
     """`p.data.mul_()` does not bump the version counter the operand cache keys on: the stale bf16 copies are used
     until `refresh_weights()` is called (documented on the method)."""

@@ -167,6 +167,7 @@ class EncoderContext:
     rstd_f: Optional[torch.Tensor] = None
     drop: Optional["DropPlan"] = None
     video_shape: Optional[Tuple[int, ...]] = None
+    checkpointed: bool = False          # blocks hold only x_in; the backward recomputes the rest
 
 
 @dataclass
@@ -214,9 +215,13 @@ class EncoderEngine:
         return B, grid, N
 
     # ---------------------------------------------------------------- forward
-    def forward(self, P: Dict[str, torch.Tensor], video: torch.Tensor, save: bool, drop: Optional[DropPlan] = None):
+    def forward(self, P: Dict[str, torch.Tensor], video: torch.Tensor, save: bool, drop: Optional[DropPlan] = None,
+                checkpoint: bool = False):
         """P: name -> f32 device tensor (parameters and the rope.inv_freq_* buffers).
         drop: training-mode dropout plan, None for the eval-mode arithmetic.
+        checkpoint (with save): keep only every block's input and let the backward run the block's forward again
+        (swm:807-811: activation checkpointing per block); the dropout masks are functions of their keys, so the second
+        forward reproduces the first bit for bit.
         Returns (features (B,N,D) f32, EncoderContext or None)."""
         cfg = self.cfg
         dev = video.device
@@ -246,59 +251,17 @@ class EncoderEngine:
         if drop is not None and (len(drop.p) != cfg.depth or len(drop.keys) != cfg.depth):
             raise ValueError("dropout plan does not match the encoder depth")
 
-        # without a backward the activations of one block are recycled for the next
+        # without a backward -- or when the backward recomputes them -- the activations of one block are recycled for
+        # the next
         scratch: Dict[str, torch.Tensor] = {}
-
-        def buf(name, cols, dtype):
-            if save:
-                return new(cols, dtype)
-            t = scratch.get(name)
-            if t is None:
-                t = scratch[name] = new(cols, dtype)
-            return t
-
-        def stat(name):
-            if save:
-                return torch.empty(M, dtype=F32, device=dev)
-            t = scratch.get(name)
-            if t is None:
-                t = scratch[name] = torch.empty(M, dtype=F32, device=dev)
-            return t
-
+        keep = save and not checkpoint
+        if ctx is not None:
+            ctx.checkpointed = checkpoint
         for i in range(cfg.depth):
-            p = f"blocks.{i}."
-            mean1, rstd1 = stat("mean1"), stat("rstd1")
-            ln1 = buf("ln1", D, BF16)
-            ops.layernorm_fwd(x, P[p + "norm1.weight"], P[p + "norm1.bias"], ln1, mean1, rstd1, LN_EPS)
-            qkv = buf("qkv", 3 * D, BF16)
-            ops.gemm_nt(ln1, Wc.fwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, qkv)
-            ops.rope3d_qk_(qkv, tables, grid)
-            attn = buf("attn", D, BF16)
-            lse2 = torch.empty(B * H, N, dtype=F32, device=dev) if save else scratch.setdefault(
-                "lse2", torch.empty(B * H, N, dtype=F32, device=dev))
-            pa, p1, p2 = drop.p[i] if drop is not None else (0.0, 0.0, 0.0)
-            ka, k1, k2 = drop.keys[i] if drop is not None else (0, 0, 0)
-            ops.attn_fwd(qkv, B, N, H, attn, lse2, drop_key=ka, drop_p=pa)
-            x_mid = buf("x_mid", D, F32) if save else buf("x_mid" + str(i & 1), D, F32)
-            ops.gemm_nt(attn, Wc.fwd(p + "out", P[p + "attn.out_proj.weight"]), ops.EPI_F32, x_mid, resid=x)
-            mean2, rstd2 = stat("mean2"), stat("rstd2")
-            ln2 = buf("ln2", D, BF16)
-            ops.layernorm_fwd(x_mid, P[p + "norm2.weight"], P[p + "norm2.bias"], ln2, mean2, rstd2, LN_EPS)
-            act = buf("act", 4 * D, BF16)
-            # both MLP dropouts ride in the GEMM epilogues; the saved activation is the dropped one
+            x_next, saved = self._block_forward(P, i, x, B, N, grid, tables, drop, keep, scratch,
+                                                fresh_output=save)
             if save:
-                pre = new(4 * D, BF16)
-                ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BIAS_GELU, pre, out2=act,
-                            bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
-            else:       # nothing is kept for a backward: the pre-activation (half of this GEMM's output bytes) is not written
-                pre = None
-                ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_GELU_ONLY, act,
-                            bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
-            x_next = buf("x_out", D, F32) if save else buf("x_out" + str(i & 1), D, F32)
-            ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next,
-                        bias=P[p + "mlp.3.bias"], resid=x_mid, drop_key=k2, drop_p=p2)
-            if save:
-                ctx.blocks.append(_BlockSaved(x, mean1, rstd1, ln1, qkv, attn, lse2, x_mid, mean2, rstd2, ln2, pre, act))
+                ctx.blocks.append(saved if keep else _BlockSaved(x, *([None] * 12)))
             x = x_next
 
         y = new(D, F32)
@@ -307,6 +270,72 @@ class EncoderEngine:
         if save:
             ctx.x_last, ctx.mean_f, ctx.rstd_f = x, mean_f, rstd_f
         return y.view(B, N, D), ctx
+
+    def _block_forward(self, P, i: int, x: torch.Tensor, B: int, N: int, grid, tables, drop: Optional[DropPlan],
+                       keep: bool, scratch: Dict[str, torch.Tensor], fresh_output: bool, need_output: bool = True):
+        """One block (swm:705-714) from its input x (M, D) f32.  keep: every intermediate gets its own buffer and comes
+        back as a _BlockSaved; otherwise intermediates live in `scratch` (recycled from block to block) and the
+        pre-activation is not written at all.  fresh_output: the block's output gets a buffer of its own (it is some
+        later computation's saved input) instead of one of two alternating scratch buffers.  need_output = False
+        stops after the first MLP layer (the recomputation in a checkpointed backward has no use for the block's
+        output)."""
+        cfg = self.cfg
+        dev = x.device
+        M, D, H = B * N, cfg.dim, cfg.heads
+        Wc = self.weights
+        p = f"blocks.{i}."
+
+        def buf(name, cols, dtype):
+            if keep:
+                return torch.empty(M, cols, dtype=dtype, device=dev)
+            t = scratch.get(name)
+            if t is None:
+                t = scratch[name] = torch.empty(M, cols, dtype=dtype, device=dev)
+            return t
+
+        def stat(name):
+            if keep:
+                return torch.empty(M, dtype=F32, device=dev)
+            t = scratch.get(name)
+            if t is None:
+                t = scratch[name] = torch.empty(M, dtype=F32, device=dev)
+            return t
+
+        mean1, rstd1 = stat("mean1"), stat("rstd1")
+        ln1 = buf("ln1", D, BF16)
+        ops.layernorm_fwd(x, P[p + "norm1.weight"], P[p + "norm1.bias"], ln1, mean1, rstd1, LN_EPS)
+        qkv = buf("qkv", 3 * D, BF16)
+        ops.gemm_nt(ln1, Wc.fwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, qkv)
+        ops.rope3d_qk_(qkv, tables, grid)
+        attn = buf("attn", D, BF16)
+        lse2 = torch.empty(B * H, N, dtype=F32, device=dev) if keep else scratch.setdefault(
+            "lse2", torch.empty(B * H, N, dtype=F32, device=dev))
+        pa, p1, p2 = drop.p[i] if drop is not None else (0.0, 0.0, 0.0)
+        ka, k1, k2 = drop.keys[i] if drop is not None else (0, 0, 0)
+        ops.attn_fwd(qkv, B, N, H, attn, lse2, drop_key=ka, drop_p=pa)
+        x_mid = buf("x_mid", D, F32)
+        ops.gemm_nt(attn, Wc.fwd(p + "out", P[p + "attn.out_proj.weight"]), ops.EPI_F32, x_mid, resid=x)
+        mean2, rstd2 = stat("mean2"), stat("rstd2")
+        ln2 = buf("ln2", D, BF16)
+        ops.layernorm_fwd(x_mid, P[p + "norm2.weight"], P[p + "norm2.bias"], ln2, mean2, rstd2, LN_EPS)
+        act = buf("act", 4 * D, BF16)
+        # both MLP dropouts ride in the GEMM epilogues; the saved activation is the dropped one
+        if keep:
+            pre = torch.empty(M, 4 * D, dtype=BF16, device=dev)
+            ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BIAS_GELU, pre, out2=act,
+                        bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
+        else:           # nothing is kept for a backward: the pre-activation (half of this GEMM's output bytes) is not written
+            pre = None
+            ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_GELU_ONLY, act,
+                        bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
+        x_next = None
+        if need_output:
+            # the output must not land in the buffer the input lives in: alternate between two when recycling
+            x_next = torch.empty(M, D, dtype=F32, device=dev) if (keep or fresh_output) else buf("x_out" + str(i & 1), D, F32)
+            ops.gemm_nt(act, Wc.fwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_F32, x_next,
+                        bias=P[p + "mlp.3.bias"], resid=x_mid, drop_key=k2, drop_p=p2)
+        saved = _BlockSaved(x, mean1, rstd1, ln1, qkv, attn, lse2, x_mid, mean2, rstd2, ln2, pre, act) if keep else None
+        return x_next, saved
 
     # ---------------------------------------------------------------- backward
     def backward(self, P: Dict[str, torch.Tensor], ctx: EncoderContext, grad_out: torch.Tensor,
@@ -367,6 +396,9 @@ class EncoderEngine:
         for i in reversed(range(cfg.depth)):
             p = f"blocks.{i}."
             s = ctx.blocks[i]
+            if ctx.checkpointed:        # only the block's input was kept: run its forward again, now keeping everything
+                _, s = self._block_forward(P, i, s.x_in, B, N, grid, tables, drop, True, {}, fresh_output=False,
+                                           need_output=False)
             flat = flat_next
             pa, p1, p2 = drop.p[i] if drop is not None else (0.0, 0.0, 0.0)
             ka, k1, k2 = drop.keys[i] if drop is not None else (0, 0, 0)

@@ -264,7 +264,8 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, module: "VideoViTEncoder", video: torch.Tensor, *params: torch.Tensor):
         P = module._tensor_table(params)
         save = any(ctx.needs_input_grad[1:])
-        out, ectx = module._engine.forward(P, video, save=save, drop=module._dropout_plan())
+        out, ectx = module._engine.forward(P, video, save=save, drop=module._dropout_plan(),
+                                           checkpoint=save and module._checkpointing(video))
         ctx.module, ctx.ectx, ctx.P = module, ectx, P
         return out
 
@@ -295,9 +296,12 @@ class VideoViTEncoder(nn.Module):
         self.blocks = nn.ModuleList([VideoViTBlock(embed_dim, num_heads, dict(_ROPE_SPLIT), 4.0, 0.1)
                                      for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
-        # 288 GB of HBM hold every activation of ViT-L at batch 32 (~60 GB): nothing is recomputed, the
-        # flag is kept for interface compatibility only.
+        # Activation checkpointing per block (swm:807-811: when the flag is set AND the module is in training mode).
+        # 288 GB of HBM hold every activation of ViT-L at batch 32 (~60 GB), so under the default policy "auto" the
+        # flag only takes effect when the activations would not fit the memory that is free; "always" recomputes
+        # whenever the reference would, "never" ignores the flag.
         self.use_grad_checkpoint = use_grad_checkpoint
+        self.checkpoint_policy = "auto"
         self._cfg = EncoderConfig(depth=depth, heads=num_heads, dim=embed_dim, tubelet=tuple(tubelet_size),
                                   in_channels=in_channels)
         self._param_order = encoder_param_names(depth)
@@ -322,6 +326,23 @@ class VideoViTEncoder(nn.Module):
     def set_grad_reducer(self, reducer) -> None:
         """Attach a `vit_amd.ddp.BucketReducer`: gradients are then averaged across ranks inside backward."""
         self._grad_reducer = reducer
+
+    ACTIVATION_BYTES_PER_TOKEN_AND_BLOCK = 36 * 1024 + 16     # x 4D, LN1 2D, qkv 6D, attn 2D, x_mid 4D, LN2 2D, MLP 16D; stats
+
+    def _checkpointing(self, video: torch.Tensor) -> bool:
+        """Whether this forward keeps only the blocks' inputs and lets the backward recompute the rest."""
+        if not (self.use_grad_checkpoint and self.training) or self.checkpoint_policy == "never":
+            return False
+        if self.checkpoint_policy == "always":
+            return True
+        if self.checkpoint_policy != "auto":
+            raise ValueError(f"checkpoint_policy must be 'auto', 'always' or 'never', not {self.checkpoint_policy!r}")
+        tt, th, tw = self._cfg.tubelet
+        tokens = video.shape[0] * (video.shape[2] // tt) * (video.shape[3] // th) * (video.shape[4] // tw)
+        need = tokens * self._cfg.depth * self.ACTIVATION_BYTES_PER_TOKEN_AND_BLOCK
+        free, _ = torch.cuda.mem_get_info(video.device)
+        free += torch.cuda.memory_reserved(video.device) - torch.cuda.memory_allocated(video.device)   # torch's own free blocks
+        return need > 0.8 * free
 
     def _dropout_plan(self) -> Optional[DropPlan]:
         """Training mode: the probabilities of each block's nn.Dropout modules (swm:263, 700-702; 0.1 as built,
