@@ -150,19 +150,21 @@ class _AllGather(torch.autograd.Function):
     def forward(ctx, x, group):
         world = dist.get_world_size(group)
         rank = dist.get_rank(group)
-        n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
+        # RCCL gathers device tensors; any other backend (gloo) is given host tensors
+        via = x.device if (dist.get_backend(group) == "nccl" or not x.is_cuda) else torch.device("cpu")
+        n = torch.tensor([x.shape[0]], dtype=torch.int64, device=via)
         sizes = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(sizes, n, group=group)
         sizes = [int(s) for s in sizes]
         biggest = max(sizes)
-        mine = x.contiguous()
+        mine = x.detach().contiguous().to(via)
         if mine.shape[0] < biggest:
             pad = mine.new_zeros((biggest - mine.shape[0],) + tuple(mine.shape[1:]))
             mine = torch.cat([mine, pad], dim=0)
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
         ctx.begin, ctx.n = sum(sizes[:rank]), sizes[rank]
-        return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+        return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0).to(x.device)
 
     @staticmethod
     def backward(ctx, g):
