@@ -172,3 +172,28 @@ def test_rotary_helpers_match_their_definition():
                  lambda: M.VideoViTBlock(1024, 16)(q)):
         with pytest.raises(_lib.VitAmdError):
             call()
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """include/vit_amd.h is the C-ABI boundary: a C99 translation unit (-pedantic) that includes it must compile, link
+    against vit_amd/libvit_amd.so and call the entry points that need no device."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    from vit_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "vit_amd.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    printf("%d %lld %lld\\n", va_version(), (long long)va_attn_mask_words(200),\n'
+                   '           (long long)va_attn_bwd_workspace_bytes(2, 64, 16));\n'
+                   '    return va_last_error() != 0 ? 0 : 1;\n}\n')
+    exe = tmp_path / "abi"
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                    "-o", str(exe), "-L", lib_dir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + lib_dir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) >= 100
+    assert int(out[1]) == 200 * 2 * 4          # N * 2 * ceil(N / 64) words per [N, N] mask
+    assert int(out[2]) == 5 * 2 * 16 * 64 * 4  # five floats per (batch, head, query)
