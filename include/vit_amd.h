@@ -139,7 +139,7 @@ int va_rope3d_qk_indexed(void* qkv, const float* cos_t, const float* sin_t, cons
  * q,k,v: bf16, element (b, n, h, d) at ((b*N + n)*ld + h*hd + d) of the respective base pointer (so the
  * three thirds of one packed qkv buffer can be passed with ld = 3*D).  o likewise with ldo.
  * lse2[b*H + h][n] f32 receives log2-sum-exp of the scaled scores (needed by the backward).
- * hd in {64, 128}. */
+ * hd in {32, 64, 128} (32, 16 or 8 heads at width 1024). */
 int va_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int64_t B, int64_t N, int64_t H,
                 int64_t hd, int64_t ldqkv, int64_t ldo, va_stream_t stream);
 /* Same with the predictor's block-causal mask (BlockCausalMask.create_mask, swm:1008-1028, as used by

@@ -170,7 +170,7 @@ def attn_reference(qkv, B, N, H, mask):
 
 
 @pytest.mark.parametrize("B,N,H,p", [(2, 8, 16, 0.1), (1, 193, 16, 0.1), (2, 256, 16, 0.1), (1, 640, 16, 0.25),
-                                     (2, 18, 8, 0.1), (1, 300, 8, 0.1), (1, 512, 8, 0.5)])
+                                     (2, 18, 8, 0.1), (1, 300, 8, 0.1), (1, 512, 8, 0.5), (1, 193, 32, 0.1), (2, 256, 32, 0.25)])
 def test_attention_dropout_fwd_bwd(ops, dev, B, N, H, p):
     D, key = 1024, 0x1234ABCD + N
     qkv = rnd((B * N, 3 * D), dev, 21, dtype=BF16)

@@ -87,7 +87,8 @@ def test_input_gradient_only_and_ragged_clip(swm):
     assert (v_ref.grad[:, :, 4:] == 0).all()
 
 
-@pytest.mark.parametrize("depth,heads,B,frames,img", [(2, 16, 2, 8, 64), (1, 8, 3, 4, 80), (1, 16, 2, 16, 224)])
+@pytest.mark.parametrize("depth,heads,B,frames,img", [(2, 16, 2, 8, 64), (1, 8, 3, 4, 80), (1, 16, 2, 16, 224),
+                                                      (2, 32, 2, 8, 64)])
 def test_encoder_matches_oracle_full_tensors(swm, depth, heads, B, frames, img):
     """Full-tensor comparison of outputs and of every gradient with the fp32 CPU oracle; the last case is
     the reference's CPU-runnable clip shape (16 x 224 x 224, 1568 tokens, batch 2) at depth 1."""

@@ -224,7 +224,8 @@ def attn_reference(qkv, B, N, H):
 
 
 @pytest.mark.parametrize("B,N,H", [(2, 8, 16), (1, 200, 16), (2, 1568, 16), (1, 2048, 16), (2, 18, 8), (1, 300, 8),
-                                   (1, 1024, 8), (1, 8192, 16), (1, 8200, 8)])   # the last two: 64-frame clips
+                                   (1, 1024, 8), (1, 8192, 16), (1, 8200, 8),   # the last two: 64-frame clips
+                                   (2, 8, 32), (1, 300, 32), (1, 2048, 32)])     # 32 heads: head dim 32
 def test_attention_fwd_bwd(ops, dev, B, N, H):
     D = 1024
     qkv = rnd((B * N, 3 * D), dev, 11, dtype=BF16)
@@ -270,7 +271,8 @@ def _masks(kind, B, N, H, dev):
 
 @pytest.mark.parametrize("B,N,H,kind", [(2, 8, 16, "random"), (1, 200, 16, "random"), (2, 300, 8, "per_batch"),
                                         (2, 256, 16, "per_head"), (1, 1024, 16, "future_only"), (1, 1000, 8, "future_only"),
-                                        (2, 210, 16, "causal7"), (1, 2048, 16, "band"), (1, 2048, 8, "random")])
+                                        (2, 210, 16, "causal7"), (1, 2048, 16, "band"), (1, 2048, 8, "random"),
+                                        (2, 300, 32, "per_batch"), (1, 1024, 32, "future_only")])
 def test_attention_with_explicit_mask_fwd_bwd(ops, dev, B, N, H, kind):
     """`scores.masked_fill(attn_mask, -inf)` before the softmax (swm:316-323) against the fp32 formula, forward and
     backward, for masks of every broadcast shape; same tolerances as the unmasked kernels."""

@@ -27,6 +27,7 @@ constexpr int TILE_ROWS = 64;
 
 template <int HD>
 VA_DEVINL int swz(int row) {
+    if (HD == 32) return (row >> 2) & 3;                                // 4 chunks per 64-byte row
     if (HD == 64) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);   // 8 chunks per 128-byte row
     return ((row & 3) << 2) | ((row >> 2) & 3);                          // 16 chunks per 256-byte row
 }
@@ -153,7 +154,7 @@ VA_DEVINL HeadBlock head_block() {
 
 // LDS ring depth of the forward kernel: three 16 KiB slots at head dim 64 (three workgroups per CU still
 // fit), two 32 KiB slots at head dim 128.
-constexpr int fwd_ring_slots(int hd) { return hd == 64 ? 3 : 2; }
+constexpr int fwd_ring_slots(int hd) { return hd <= 64 ? 3 : 2; }
 
 // ------------------------------------------------------------------------------------------------
 // forward.  The loop is bound by vector-instruction issue (32 exponentials + the bookkeeping per lane and
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
         // hd 64: every LDS read of a phase is issued before its first MFMA (the fragments fit the register
         // file); hd 128: fragments are read next to their use.
-        constexpr bool PRELOAD = HD == 64;
+        constexpr bool PRELOAD = HD <= 64;
         bf16x8_t kf[2][KS];
         if (PRELOAD) {
 #pragma unroll
@@ -428,7 +429,7 @@ VA_DEVINL void split3_bf16(float x, uint32_t& d0, uint32_t& d1) {
 // NEG_DELTA and, together with -lse2, as the 16-byte record the dK/dV pass feeds to the matrix pipe.
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool RAGGED, bool DROP = false, bool BITS = false>
-__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, HD <= 64 ? 2 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
                                                           const bf16_t* __restrict__ DO,
                                                           const float* __restrict__ LSE2,
@@ -585,7 +586,7 @@ template <int HD, bool DROP>   // Q | dO | records | DROP: f32 -delta of the til
 constexpr int dkv_stage_bytes() { return 2 * TILE_ROWS * HD * 2 + TILE_ROWS * 16 + (DROP ? TILE_ROWS * 4 : 0); }
 
 template <int HD, bool RAGGED, bool DROP = false, bool BITS = false>
-__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, HD <= 64 ? 2 : 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
                                                            const u32x4_t* __restrict__ AUX,
                                                            const float* __restrict__ NEG_DELTA, bf16_t* __restrict__ DK,
@@ -760,7 +761,7 @@ int set_lds(KernT kern, int bytes, bool* flags, const char* who) {
 
 int check_common(const char* who, int64_t B, int64_t N, int64_t H, int64_t hd, int64_t ldqkv, int64_t ldo) {
     VA_CHECK_ARG(B > 0 && N > 0 && H > 0, "%s: empty problem", who);
-    VA_CHECK_ARG(hd == 64 || hd == 128, "%s: head dim %lld not supported (64 or 128)", who, (long long)hd);
+    VA_CHECK_ARG(hd == 32 || hd == 64 || hd == 128, "%s: head dim %lld not supported (32, 64 or 128)", who, (long long)hd);
     VA_CHECK_ARG(ldqkv >= H * hd && ldo >= H * hd, "%s: leading dimension smaller than H*hd", who);
     VA_CHECK_ARG(ldqkv % 8 == 0 && ldo % 8 == 0, "%s: leading dimensions must keep 16-byte alignment", who);
     VA_CHECK_ARG(B * H < 65536 && N < (1 << 24), "%s: B*H or N too large for the launch grid", who);
@@ -854,6 +855,9 @@ static int attn_fwd_entry(const char* who, const void* q, const void* k, const v
     VA_CHECK_ARG(q && k && v && o && lse2, "%s: null operand", who);
     if (int e = check_common(who, B, N, H, hd, ldqkv, ldo)) return e;
     VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "%s: misaligned operand", who);
+    if (hd == 32)
+        return fwd_launch<32>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, (int)B, (int)N,
+                              (int)H, ldqkv, ldo, (int)tpt, drop, stream, mask);
     if (hd == 64)
         return fwd_launch<64>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse2, (int)B, (int)N,
                               (int)H, ldqkv, ldo, (int)tpt, drop, stream, mask);
@@ -899,6 +903,10 @@ static int attn_bwd_entry(const char* who, const void* q, const void* k, const v
     VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq |
                   (uintptr_t)dk | (uintptr_t)dv) % 16 == 0,
                  "%s: misaligned operand", who);
+    if (hd == 32)
+        return bwd_launch<32>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
+                              lse2, workspace, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo,
+                              lddqkv, drop, stream, mask);
     if (hd == 64)
         return bwd_launch<64>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
                               lse2, workspace, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, (int)B, (int)N, (int)H, ldqkv, ldo,

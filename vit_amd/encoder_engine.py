@@ -61,8 +61,8 @@ class EncoderConfig:
             raise ops._lib.VitAmdError("the encoder kernels are specialised for width 1024 (the only width the "
                                        "reference's 256/384/384 RoPE split admits)")
         hd = self.dim // self.heads
-        if self.dim % self.heads or hd not in (64, 128):
-            raise ops._lib.VitAmdError(f"head dim {hd} (heads={self.heads}) has no attention kernel; use 16 or 8 heads")
+        if self.dim % self.heads or hd not in (32, 64, 128):
+            raise ops._lib.VitAmdError(f"head dim {hd} (heads={self.heads}) has no attention kernel; use 32, 16 or 8 heads")
 
 
 class WeightCache:

@@ -217,8 +217,8 @@ class RoPEMultiheadAttention(nn.Module):
         `attn_mask` (True = masked): None, or any boolean mask `masked_fill` would broadcast over (B, heads, N, N)."""
         _need_device(x, "RoPEMultiheadAttention.forward")
         B, N, C = x.shape
-        if C != self.embed_dim or self.head_dim not in (64, 128) or C % 128:
-            raise VitAmdError(f"no attention kernel for embed_dim {C} with head_dim {self.head_dim} (64 or 128 needed)")
+        if C != self.embed_dim or self.head_dim not in (32, 64, 128) or C % 128:
+            raise VitAmdError(f"no attention kernel for embed_dim {C} with head_dim {self.head_dim} (32, 64 or 128 needed)")
         p = self.dropout.p if self.dropout.training else 0.0
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.qkv_proj.weight.requires_grad or
                                                   self.out_proj.weight.requires_grad)
