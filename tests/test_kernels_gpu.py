@@ -529,3 +529,17 @@ def test_masked_pool_matches_future_masking_of_the_oracle():
         n_first = STM.first_masked_row(Tp * per_t, Tp, ratio)
         assert n_first == int(keep[0].sum())
         assert torch.allclose(ops.token_pool(x.cuda(), n_first).cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_c_abi_from_a_plain_host_program():
+    """examples/c_abi_demo (built by __graft_entry__.build()): a C++ host program with hipMalloc'd buffers calls
+    va_layernorm_fwd and va_gemm_nt through include/vit_amd.h -- no Python, no torch in that process -- checks them
+    against a double-precision host computation and checks that an invalid call returns an error code."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "c_abi_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    env = {k: v for k, v in os.environ.items() if k != "LD_LIBRARY_PATH"}     # its own HIP runtime, not torch's
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout and "rejected as expected" in r.stdout
