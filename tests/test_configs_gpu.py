@@ -70,6 +70,41 @@ def test_vit_l_depth24_one_clip_matches_oracle(swm):
     assert not bad, bad
 
 
+def test_training_mode_at_2048_tokens_matches_oracle_with_the_same_masks(swm):
+    """Training mode (the three p = 0.1 dropouts of every block, swm:263, 700-702) at the real token count -- one
+    16x256x256 clip, 2048 tokens, 16 heads, three blocks -- with activation checkpointing on top (the recomputed
+    forward must regenerate the very same masks): output, every parameter gradient and the clip's gradient against the
+    oracle run with masks rebuilt from the same keys (the oracle restates the documented hash of include/vit_amd.h)."""
+    from vit_amd.encoder_engine import DropPlan
+    depth, heads = 3, 16
+    enc, sd = _filled_encoder(swm, depth, heads, 16, 256)
+    enc.train()
+    enc.use_grad_checkpoint, enc.checkpoint_policy = True, "always"
+    ps = [(0.1, 0.1, 0.1)] * depth
+    keys = [(101, 202, 303), (0xFFFFFFF0, 0x80000001, 12345), (7, 0xDEADBEEF, 0x7FFFFFFF)]
+    enc._dropout_plan = lambda: DropPlan(ps, keys)
+    video = R.hashed_uniform("cfg2.train.video", (1, 3, 16, 256, 256), 1.0)
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items() if "inv_freq" not in k}
+    v_ref = video.clone().requires_grad_(True)
+    ref = R.encoder_forward(P, v_ref, depth, heads, drop_p=ps, drop_keys=keys)
+    gy = R.hashed_uniform("cfg2.train.gy", tuple(ref.shape), 1.0)
+    (ref * gy).sum().backward()
+    v = video.cuda().requires_grad_(True)
+    y = enc(v)
+    (y * gy.cuda()).sum().backward()
+    with torch.no_grad():
+        plain = R.encoder_forward({k: t.detach() for k, t in P.items()}, video, depth, heads)
+    assert rel(plain, ref) > 0.05                                  # the masks really change the result
+    e_out, e_in = rel(y, ref), rel(v.grad, v_ref.grad)
+    errs = {k: rel(p.grad, P[k].grad) for k, p in enc.named_parameters()}
+    worst = max(errs, key=errs.get)
+    print(f"[training mode, 2048 tokens] output rel {e_out:.2e}; input-grad rel {e_in:.2e}; worst parameter-grad rel "
+          f"{errs[worst]:.2e} ({worst})")
+    assert e_out < OUT_TOL and e_in < GRAD_TOL
+    bad = {k: e for k, e in errs.items() if not e < GRAD_TOL}
+    assert not bad, bad
+
+
 def test_config1_depth12_batch2_forward_and_jepa_l1_step(swm):
     """The reference's CPU-sized case at its real depth: 1024/12/16, two 16x224x224 clips.  Forward of the online and
     the target encoder against the oracle; the L1 latent loss of the JEPA step against the oracle's; and the encoder
