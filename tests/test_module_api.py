@@ -197,3 +197,32 @@ def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
     assert int(out[0]) >= 100
     assert int(out[1]) == 200 * 2 * 4          # N * 2 * ceil(N / 64) words per [N, N] mask
     assert int(out[2]) == 5 * 2 * 16 * 64 * 4  # five floats per (batch, head, query)
+
+
+def test_every_entry_point_rejects_null_arguments_with_a_message():
+    """Nothing may cross the C boundary as a crash or an exception: every compute entry point called with null
+    pointers and zero sizes returns a negative code and leaves a message naming itself (run in a child process, so a
+    crash would fail this test instead of ending the test run).  No device is needed: the checks come first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from vit_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "for name, (res, args) in _lib.SIGNATURES.items():\n"
+        "    if name in ('va_version', 'va_last_error'):\n"
+        "        continue\n"
+        "    zeros = [None if a is ctypes.c_void_p else (0.0 if a is ctypes.c_float else 0) for a in args]\n"
+        "    rc = getattr(lib, name)(*zeros)\n"
+        "    if res is ctypes.c_int:\n"
+        "        msg = lib.va_last_error().decode()\n"
+        "        assert rc < 0, (name, rc)\n"
+        "        assert msg.startswith('va_'), (name, msg)\n"
+        "    else:\n"
+        "        assert rc == 0, (name, rc)      # the size queries answer 0 for an empty problem\n"
+        "print('checked', len(_lib.SIGNATURES) - 2)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "checked" in r.stdout
