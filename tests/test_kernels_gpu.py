@@ -115,7 +115,7 @@ def test_gemm_nt_layout_is_not_transposed(ops, dev):
 
 
 @pytest.mark.parametrize("tile,M", [(128, 700), (256, 700), (1256, 700), (2256, 700), (256, 256 * 9), (4256, 700),
-                                    (4256, 256 * 9), (4256, 256 * 1100 + 3)])
+                                    (4256, 256 * 9), (4256, 256 * 1100 + 3), (0, 1), (0, 255), (0, 257), (4256, 1), (256, 1)])
 def test_gemm_nt_epilogues(ops, dev, tile, M):
     N, K = 1024, 1024
     x = rnd((M, K), dev, 3, dtype=BF16)
@@ -225,7 +225,8 @@ def attn_reference(qkv, B, N, H):
 
 @pytest.mark.parametrize("B,N,H", [(2, 8, 16), (1, 200, 16), (2, 1568, 16), (1, 2048, 16), (2, 18, 8), (1, 300, 8),
                                    (1, 1024, 8), (1, 8192, 16), (1, 8200, 8),   # the last two: 64-frame clips
-                                   (2, 8, 32), (1, 300, 32), (1, 2048, 32)])     # 32 heads: head dim 32
+                                   (2, 8, 32), (1, 300, 32), (1, 2048, 32),      # 32 heads: head dim 32
+                                   (3, 1, 16), (2, 33, 8), (1, 65, 16), (2, 127, 32), (1, 129, 16)])   # around the tile edges
 def test_attention_fwd_bwd(ops, dev, B, N, H):
     D = 1024
     qkv = rnd((B * N, 3 * D), dev, 11, dtype=BF16)
@@ -243,7 +244,10 @@ def test_attention_fwd_bwd(ops, dev, B, N, H):
     ops.attn_bwd(qkv, out, d_out, lse2, dqkv, B, N, H)
     assert torch.isfinite(dqkv.float()).all()
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
-        assert rel_err(dqkv[:, sl], leaf.grad[:, sl]) < 1.5e-2, name
+        if N == 1 and name != "dv":      # a single key: the softmax is the constant 1, so dQ = dK = 0 exactly
+            assert dqkv[:, sl].float().abs().max().item() < 1e-5, name
+        else:
+            assert rel_err(dqkv[:, sl], leaf.grad[:, sl]) < 1.5e-2, name
 
 
 def _masks(kind, B, N, H, dev):
