@@ -25,6 +25,10 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 def _need(t: torch.Tensor, dtype, name: str, inner_contig: bool = True):
     if not t.is_cuda:
         raise _lib.VitAmdError(f"{name}: tensor must live on a HIP device (vit_amd has no CPU path)")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's stream: a tensor of another device would be a wild pointer there
+        raise _lib.VitAmdError(f"{name}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                               "wrap the call in torch.cuda.device(tensor.device) (VideoViTEncoder.forward does)")
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if inner_contig and t.dim() >= 1 and t.stride(-1) != 1:

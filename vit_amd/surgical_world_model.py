@@ -273,11 +273,12 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         module = ctx.module
         reducer = module._grad_reducer
-        grads = module._engine.backward(ctx.P, ctx.ectx, grad_out,
-                                        on_block_done=reducer.submit if reducer is not None else None,
-                                        input_grad=ctx.needs_input_grad[1])
-        if reducer is not None:
-            reducer.finish()
+        with torch.cuda.device(grad_out.device):
+            grads = module._engine.backward(ctx.P, ctx.ectx, grad_out,
+                                            on_block_done=reducer.submit if reducer is not None else None,
+                                            input_grad=ctx.needs_input_grad[1])
+            if reducer is not None:
+                reducer.finish()
         ctx.ectx = None
         names = module._param_order
         return (None, grads.get("video")) + tuple(grads[n] if need else None
@@ -379,7 +380,8 @@ class VideoViTEncoder(nn.Module):
             if p.device != video.device or p.dtype != torch.float32:
                 raise VitAmdError(f"parameter {n} must be float32 on {video.device} (master weights stay f32; "
                                   "the engine keeps its own bf16 operand copies)")
-        return _EncoderFn.apply(self, video, *params)
+        with torch.cuda.device(video.device):        # the kernels go to the current device's stream
+            return _EncoderFn.apply(self, video, *params)
 
 
 # =====================================================================================================
