@@ -14,6 +14,9 @@ EPI_BF16, EPI_BIAS_GELU, EPI_F32, EPI_GELU_BWD, EPI_GELU_ONLY = 0, 1, 2, 3, 4
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+_current_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)     # the binding itself: this runs per tensor
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -25,9 +28,9 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 def _need(t: torch.Tensor, dtype, name: str, inner_contig: bool = True):
     if not t.is_cuda:
         raise _lib.VitAmdError(f"{name}: tensor must live on a HIP device (vit_amd has no CPU path)")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _current_device():
         # kernels are launched on the CURRENT device's stream: a tensor of another device would be a wild pointer there
-        raise _lib.VitAmdError(f"{name}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+        raise _lib.VitAmdError(f"{name}: tensor is on {t.device} but the current device is cuda:{_current_device()}; "
                                "wrap the call in torch.cuda.device(tensor.device) (VideoViTEncoder.forward does)")
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
