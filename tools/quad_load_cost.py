@@ -1,0 +1,26 @@
+"""Timing-only variants of the four-wave GEMM (debug build; results are wrong by construction): what the operand loads
+cost in the main loop.  4256 real kernel, 4257 no loads at all, 4263 the same bytes fetched as whole 128-byte lines into
+registers and dropped, 4264 the same plus one ds_write_b128 per load into the ring slot."""
+import math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vit_amd import ops
+dev = torch.device("cuda:0")
+M = 65536
+def timed(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+for name, N, K in [("qkv", 3072, 1024), ("dfc1", 1024, 4096)]:
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    line = []
+    for tile in (4256, 4257, 4263, 4264, 4256):
+        t = min(timed(lambda: ops.gemm_nt(x, w, ops.EPI_BF16, out, tile=tile)) for _ in range(2))
+        line.append(f"{tile}: {t:.4f} ms")
+    print(name, " | ".join(line), flush=True)

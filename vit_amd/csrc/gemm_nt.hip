@@ -635,6 +635,14 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 #define VA_PIN asm volatile("" ::: "memory")
     // One stage: 64 MFMAs; the next stage's fragments are read into the registers just retired and the eight
     // loads of the stage four ahead (stage kt_load of tile `lt`) go out one per row block.
+    u32x4_t sink[2][8];          // DBG 6 / 7 only
+    auto lds_off_dbg = [&](int sl) { return (uint32_t)(uintptr_t)(lds_ptr_t)(smem + sl * STAGE_BYTES); };
+    if (DBG == 6 || DBG == 7) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sink[i][j] = (u32x4_t){0u, 0u, 0u, 0u};
+    }
     auto body = [&](auto parity, auto first, int next_slot, const Tile& lt, int kt_load, int load_slot) {
         constexpr int P = decltype(parity)::value;
         constexpr bool FIRST = decltype(first)::value;
@@ -655,7 +663,20 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
             }
             VA_PIN;
             if (DBG != 2) xf[b] = frag_x(next_slot, b);
-            if (DBG != 1) load_one(lt, kt_load, load_slot, b);
+            if (DBG == 6 || DBG == 7) {
+                // timing only: the stage's bytes fetched as whole 128-byte lines into registers (8 lanes per row) instead
+                // of 64-byte half lines into LDS; DBG 7 also writes the registers of the previous stage's loads into the slot
+                const int ld_ = b < 4 ? ldx : ldw;
+                const bf16_t* base = (b < 4 ? X + (size_t)lt.m0 * ldx : W + (size_t)lt.n0 * ldw) +
+                                     (size_t)((kt_load & 1) * 128) * ld_ + (kt_load >> 1) * 64;      // wave-uniform
+                const int q = (b & 3) * NT + tid;
+                const uint32_t voff = (uint32_t)(((q >> 3) * ld_ + (q & 7) * 8) * 2);
+                if (DBG == 7) {
+                    const uint32_t dst = lds_off_dbg(load_slot) + (uint32_t)(b * NT + tid) * 16;
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(dst), "v"(sink[P ^ 1][b]) : "memory");
+                }
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sink[P][b]) : "v"(voff), "s"(base) : "memory");
+            } else if (DBG != 1) load_one(lt, kt_load, load_slot, b);
             VA_PIN;
         };
         block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{});
@@ -775,6 +796,12 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         after_epilogue = full;
     }
     wait_vm0();   // the trailing loads must not land in LDS after the workgroup has gone
+    if (DBG == 6 || DBG == 7) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(sink[i][j]));
+    }
     // the last workgroup out rewinds the counters for the next launch that is given this set
     if (tid == 0 && atomicAdd(tk + 8, 1) == (int)gridDim.x - 1) {
 #pragma unroll
@@ -906,6 +933,8 @@ int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, 
     if (EPI == VA_EPI_BF16 && tile == 4258) return launch_quad<VA_EPI_BF16, false, 2>(X, W, M, N, K, ldx, ldw, ep, stream);
     if (EPI == VA_EPI_BF16 && tile == 4259) return launch_quad<VA_EPI_BF16, false, 3>(X, W, M, N, K, ldx, ldw, ep, stream);
     if (EPI == VA_EPI_BF16 && tile == 4261) return launch_quad<VA_EPI_BF16, false, 5>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4263) return launch_quad<VA_EPI_BF16, false, 6>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (EPI == VA_EPI_BF16 && tile == 4264) return launch_quad<VA_EPI_BF16, false, 7>(X, W, M, N, K, ldx, ldw, ep, stream);
 #endif
     if (tile == 1256) return launch_pair<256, 256, 2, 4, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
     return launch_pair<128, 128, 2, 2, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
@@ -937,7 +966,7 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
         const bool quad = epilogue == VA_EPI_BF16 || (epilogue == VA_EPI_F32 && drop_thresh16 == 0);
         tile = !big ? 128 : quad ? 4256 : 256;
     }
-    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || (tile >= 4256 && tile <= 4261)) && N % 256 == 0 && K >= 128),
+    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || (tile >= 4256 && tile <= 4264)) && N % 256 == 0 && K >= 128),
                  "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
     VA_CHECK_ARG(drop_thresh16 == 0 || tile < 4256, "va_gemm_nt_dropout: the four-wave kernel (tile %d) has no dropout epilogue", tile);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc, drop_key, drop_thresh16 << 16,
