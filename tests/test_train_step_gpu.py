@@ -47,6 +47,34 @@ def test_stage1_losses_match_oracle(env):
     assert all(torch.isfinite(p.grad).all() for p in model.encoder.parameters())
 
 
+def test_no_grad_pass_is_taken_from_the_video_view_when_nothing_is_random(env):
+    """The denoising term's no-grad pass (s1:449-451) repeats the `video` view exactly when no dropout is active, so its
+    tokens are reused: same losses, bit for bit, as with the separate pass, and one encoder pass fewer; in training
+    mode with p > 0 the separate pass is kept (its masks are its own)."""
+    swm, ts, _, _ = env
+    model = small_model(swm)
+    heads = ts.Stage1Heads().eval()
+    heads.load_state_dict(R.fill_state_dict_(heads.state_dict()))
+    heads = heads.cuda()
+    vids = [R.hashed_uniform(f"s1.reuse.{i}", (3, 3, 4, 32, 32), 1.0).cuda() for i in range(3)]
+    label = torch.tensor([0, 1, 1]).cuda()
+    calls = []
+    inner = model.encoder.forward
+    model.encoder.forward = lambda v: (calls.append(v.shape[0]), inner(v))[1]
+    for fuse in (True, False):
+        calls.clear()
+        a, pa = ts.stage1_losses(model, heads, *vids, label, fuse_views=fuse)
+        n_reuse = len(calls)
+        calls.clear()
+        b, pb = ts.stage1_losses(model, heads, *vids, label, fuse_views=fuse, reuse_tokens=False)
+        assert len(calls) == n_reuse + 1
+        assert torch.equal(a, b) and all(torch.equal(x, y) for x, y in zip(pa, pb))
+    model.train()                                  # p = 0.1 dropouts now active: the fourth pass must be made
+    calls.clear()
+    ts.stage1_losses(model, heads, *vids, label)
+    assert len(calls) == 2
+
+
 def test_optimizer_step_refreshes_operand_copies(env):
     swm, ts, _, _ = env
     model = small_model(swm)

@@ -31,5 +31,5 @@ for it in range(steps + 1):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     loss, parts = ts.stage1_step(model, heads, opt, batch, max_norm=None, encoder_grad=not frozen)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"step {it}: {dt*1e3:.1f} ms  loss {loss:.4f}  ({B/dt:.1f} samples/s; {4*B/dt:.1f} encoder clip-passes/s)  "
+    print(f"step {it}: {dt*1e3:.1f} ms  loss {loss:.4f}  ({B/dt:.1f} samples/s)  "
           f"grad norm {opt.grad_norm().item():.3f}  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)

@@ -131,25 +131,41 @@ def stage1_head_losses(heads: Stage1Heads, f_shuf, f_orig, f_aug, pooled_unmaske
 
 def stage1_losses(model, heads: Stage1Heads, video, video_aug, shuffled_video, order_label,
                   lambda_mask: float = 0.1, temperature: float = 0.07, fuse_views: bool = True,
-                  encoder_grad: bool = True, group: Optional[dist.ProcessGroup] = None):
+                  encoder_grad: bool = True, group: Optional[dist.ProcessGroup] = None,
+                  reuse_tokens: Optional[bool] = None):
     """Returns (objective, (temporal, contrastive, mask)); see `stage1_head_losses` for the objective.  `fuse_views`
     runs the three gradient-carrying views as ONE encoder pass over 3B clips (clips are independent, so the result is
     identical and every weight is read once instead of three times).  The token pooling on either side of the heads
     (the only part of them that moves more than a few megabytes) runs on the pooling kernels; the heads' small
     (B x 1024) layers are library GEMMs through torch."""
     B = video.shape[0]
+    # The denoising term's no-grad pass encodes `video` once more (s1:449-451).  When no dropout is active in the encoder
+    # (eval mode -- the frozen fine-tuning loop puts it there, ft:263-264 -- or p = 0) that pass repeats the `video`
+    # view of the passes above bit for bit, so its tokens are taken from there instead of being computed again.
+    enc = getattr(model, "encoder", None)
+    deterministic = enc is not None and not any(m.training and m.p > 0 for m in enc.modules() if isinstance(m, nn.Dropout))
+    if reuse_tokens is not None:          # False forces the separate pass (tests compare the two)
+        deterministic = deterministic and reuse_tokens
+    tokens = None
     with torch.set_grad_enabled(encoder_grad and torch.is_grad_enabled()):
         if fuse_views:
-            feats = _pool_tokens(model.encode_video(torch.cat([shuffled_video, video, video_aug], dim=0)))
+            all_tokens = model.encode_video(torch.cat([shuffled_video, video, video_aug], dim=0))
+            feats = _pool_tokens(all_tokens)
             f_shuf, f_orig, f_aug = feats[:B], feats[B:2 * B], feats[2 * B:]
+            if deterministic:
+                tokens = all_tokens[B:2 * B].detach()
         else:
             f_shuf = _pool_tokens(model.encode_video(shuffled_video))
-            f_orig = _pool_tokens(model.encode_video(video))
+            orig_tokens = model.encode_video(video)
+            f_orig = _pool_tokens(orig_tokens)
             f_aug = _pool_tokens(model.encode_video(video_aug))
+            if deterministic:
+                tokens = orig_tokens.detach()
     pooled_unmasked = pooled_all = None
     if heads.denoise_head is not None:
         with torch.no_grad():
-            tokens = model.encode_video(video)
+            if tokens is None:
+                tokens = model.encode_video(video)
             pooled_unmasked, pooled_all = _pool_unmasked(tokens, model.encoder.tubelet_embed.num_temporal_patches)
     return stage1_head_losses(heads, f_shuf, f_orig, f_aug, pooled_unmasked, pooled_all, order_label, lambda_mask,
                               temperature, group)
