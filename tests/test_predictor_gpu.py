@@ -75,6 +75,48 @@ def test_gated_delta_vs_oracle(env, B, L, H, D):
         assert torch.allclose(torch.cat([o1, o2], dim=1), out, atol=1e-5) and torch.allclose(s2, st, atol=1e-5)
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_gated_delta_small_and_zero_decays(env, D):
+    """Chunks of 16 steps whose decays multiply to less than 1e-20 (or hold a zero) take the kernel's explicit
+    update, the others the form with the decay folded into a running product; both against the sequential oracle,
+    with decays that are tiny, exactly zero, exactly one, and ordinary, chunk by chunk."""
+    ops, _ = env
+    F = torch.nn.functional
+    B, L, H = 2, 83, 3
+    q = F.normalize(R.hashed_uniform("t.gd2.q", (B, L, H, D), 1.0), dim=-1)
+    k = F.normalize(R.hashed_uniform("t.gd2.k", (B, L, H, D), 1.0), dim=-1)
+    v = R.hashed_uniform("t.gd2.v", (B, L, H, D), 1.0)
+    a = R.hashed_uniform("t.gd2.a", (B, L, H), 0.5, 0.5)
+    b = R.hashed_uniform("t.gd2.b", (B, L, H), 0.5, 0.5)
+    a[:, 16:32] = 0.04                       # product 4e-23: explicit
+    a[:, 32:48] = 0.06                       # product 3e-20: folded, close to the threshold
+    a[0, 50] = 0.0                           # a zero inside an ordinary chunk
+    a[1, 64:80] = 1.0                        # no decay at all
+    a[:, 80, 1] = 1e-30
+    s0 = R.hashed_uniform("t.gd2.s", (B, H, D, D), 0.3)
+    ref_o, ref_s = R.gated_delta_sequential(q, k, v, a, b, s0)
+    out, st = ops.gated_delta_seq(q.cuda(), k.cuda(), v.cuda(), a.cuda(), b.cuda(), s0.cuda())
+    assert torch.isfinite(out).all() and torch.isfinite(st).all()
+    assert (out.cpu() - ref_o).abs().max().item() < 5e-5
+    assert (st.cpu() - ref_s).abs().max().item() < 5e-5
+
+
+def test_gated_delta_long_sequence_stays_close(env):
+    """2064 steps (the rollout's length at 8 frames of context): the folded form must not drift from the oracle."""
+    ops, _ = env
+    F = torch.nn.functional
+    B, L, H, D = 1, 2064, 2, 128
+    q = F.normalize(R.hashed_uniform("t.gd3.q", (B, L, H, D), 1.0), dim=-1)
+    k = F.normalize(R.hashed_uniform("t.gd3.k", (B, L, H, D), 1.0), dim=-1)
+    v = R.hashed_uniform("t.gd3.v", (B, L, H, D), 1.0)
+    a = R.hashed_uniform("t.gd3.a", (B, L, H), 0.45, 0.5)
+    b = R.hashed_uniform("t.gd3.b", (B, L, H), 0.5, 0.5)
+    ref_o, ref_s = R.gated_delta_sequential(q, k, v, a, b, None)
+    out, st = ops.gated_delta_seq(q.cuda(), k.cuda(), v.cuda(), a.cuda(), b.cuda())
+    assert (out.cpu() - ref_o).abs().max().item() < 5e-5
+    assert (st.cpu() - ref_s).abs().max().item() < 5e-5
+
+
 @pytest.mark.parametrize("B,L,C,norm", [(2, 1, 1024, True), (2, 7, 1024, True), (3, 50, 2048, False), (1, 5, 256, True)])
 def test_dwconv_silu_vs_oracle(env, B, L, C, norm):
     ops, _ = env

@@ -3,10 +3,16 @@
 //  * gated_delta_kernel: the sequential recurrence of swm:523-555,
 //        S <- alpha_t * S * (I - beta_t k_t k_t^T) + beta_t v_t k_t^T,      o_t = S q_t
 //    evaluated in its rank-1 form  sk = S k;  S <- alpha*S + beta*(v - alpha*sk) k^T  (no hd^3 products).
-//    One workgroup per (batch, head); lane i keeps row i of the hd x hd state in registers for the whole
-//    sequence, so a step is two 128-long dot products and one rank-1 update per lane with no cross-lane
-//    traffic.  k/q/v/alpha/beta of 16 steps at a time are staged in LDS (double-buffered, direct-to-LDS
-//    loads) and read back as broadcasts.
+//    One workgroup of 2*hd lanes per (batch, head), the hd x hd state in registers for the whole sequence.  Lane
+//    l = 4*g + c holds rows 2g, 2g+1 of the columns {16j + 4c .. 16j + 4c + 3}: a step then needs only hd/4 values
+//    of k and of q per lane (read from LDS as 16-byte pieces, the four lanes of a quad reading 64 consecutive
+//    bytes) instead of all hd as broadcasts, and the 2*hd/64 waves of a head land on different SIMDs with a second
+//    head's waves beside them to cover the step's dependent chain (dot product -> coefficient -> update).  The two
+//    partial dot products of a lane are summed over its quad with two exchange steps that leave lanes 0,1 holding
+//    the total of row 2g and lanes 2,3 that of row 2g+1; those lanes compute the row's update coefficient, which
+//    goes back to the quad with two quad broadcasts, and one of them writes the row's output.  k/q/v/alpha/beta
+//    of 16 steps at a time are staged in LDS (double-buffered; fetched into registers a chunk ahead), and a step's
+//    operands are read from LDS while the step before it computes.
 //  * dwconv_silu_kernel: causal depthwise conv1d (4 taps, swm:452-457 with the [..., :L] cut of swm:484-486)
 //    + bias + SiLU, optionally followed by the row-wise L2 normalisation of swm:489-490.
 #include "common.h"
@@ -15,21 +21,36 @@ namespace {
 
 constexpr int GD_T = 16;   // steps per staged chunk
 
+template <bool V> struct flag { static constexpr bool value = V; };
+
+// x of another lane of the same quad; CTRL is the quad permutation (two bits per destination lane).
+template <int CTRL>
+__device__ __forceinline__ float quad_lane(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// Two values per lane, summed over the four lanes of a quad: lanes 0 and 1 return the total of p0, lanes 2 and 3
+// the total of p1.  First exchange with the lane two away (each keeps the value it will end up owning), then add the
+// neighbour's.  hi2 = bit 1 of the lane's position in its quad.
+__device__ __forceinline__ float quad_reduce_pairs(float p0, float p1, bool hi2) {
+    const float k = (hi2 ? p1 : p0) + quad_lane<0x4E>(hi2 ? p0 : p1);       // 0x4E: lanes [2,3,0,1]
+    return k + quad_lane<0xB1>(k);                                           // 0xB1: lanes [1,0,3,2]
+}
+
 template <int HD>
-__global__ __launch_bounds__(HD) void gated_delta_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(2 * HD) __attribute__((amdgpu_waves_per_eu(2))) void gated_delta_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ V, const float* __restrict__ ALPHA,
                                                          const float* __restrict__ BETA,
                                                          const float* __restrict__ STATE_IN, float* __restrict__ OUT,
                                                          float* __restrict__ STATE_OUT, int L, int H) {
-    constexpr int WAVES = HD / 64;
+    constexpr int WAVES = 2 * HD / 64;
     constexpr int ROWS_PER_PASS = WAVES * 64 * 4 / HD;          // rows one pass of 16-byte lanes covers
     constexpr int PASSES = GD_T / ROWS_PER_PASS;
     __shared__ __attribute__((aligned(16))) float ks[2][GD_T][HD];
     __shared__ __attribute__((aligned(16))) float qs[2][GD_T][HD];
     __shared__ __attribute__((aligned(16))) float vs[2][GD_T][HD];
-    __shared__ float ab[2][2][GD_T];
-    const int i = threadIdx.x, lane = i & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
+    __shared__ __attribute__((aligned(16))) float ab[2][2][GD_T];
+    const int i = threadIdx.x;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int64_t row_stride = (int64_t)H * HD;
     const float* qb = Q + (int64_t)b * L * row_stride + h * HD;
@@ -37,34 +58,52 @@ __global__ __launch_bounds__(HD) void gated_delta_kernel(const float* __restrict
     const float* vb = V + (int64_t)b * L * row_stride + h * HD;
     const float* ab_src[2] = {ALPHA + (int64_t)b * L * H + h, BETA + (int64_t)b * L * H + h};
 
-    // row i of the state as float pairs: the step arithmetic is written on pairs so that it maps to packed
-    // f32 instructions on adjacent registers
+    // the state as float pairs: the step arithmetic is written on pairs so that it maps to packed f32
+    // instructions on adjacent registers.  T[r][2j], T[r][2j+1] = row 2g + r, columns 16j + 4c .. + 3.
     typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    f32x2_t S[HD / 2];
+    constexpr int NJ = HD / 16;
+    const int cg = i & 3, row0 = (i >> 2) * 2;
+    const bool hi2 = (cg & 2) != 0;
+    const int own = row0 + (hi2 ? 1 : 0);          // the row whose totals this lane ends up with
+    f32x2_t T[2][2 * NJ];
     if (STATE_IN != nullptr) {
-        const float* src = STATE_IN + ((int64_t)bh * HD + i) * HD;
 #pragma unroll
-        for (int j = 0; j < HD; j += 4) {
-            const f32x4_t v4 = *(const f32x4_t*)(src + j);
-            S[j / 2] = (f32x2_t){v4[0], v4[1]};
-            S[j / 2 + 1] = (f32x2_t){v4[2], v4[3]};
+        for (int r = 0; r < 2; ++r) {
+            const float* src = STATE_IN + ((int64_t)bh * HD + row0 + r) * HD + 4 * cg;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x4_t v4 = *(const f32x4_t*)(src + 16 * j);
+                T[r][2 * j] = (f32x2_t){v4[0], v4[1]};
+                T[r][2 * j + 1] = (f32x2_t){v4[2], v4[3]};
+            }
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < HD / 2; ++j) S[j] = (f32x2_t){0.f, 0.f};
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 2 * NJ; ++j) T[r][j] = (f32x2_t){0.f, 0.f};
     }
 
+    // Staging of a chunk: direct-to-LDS loads issued at the start of the previous chunk and waited for at its end.
+    // They are written as assembly because the compiler, not knowing which LDS bytes such a load writes, would
+    // otherwise drain the vector-memory counter before every LDS read of the step loop.  (m0 holds nothing of the
+    // compiler's between statements in this kernel: it sets it only for instructions of this kind.)
     const int r_in_pass = i * 4 / HD, col = (i * 4) % HD;     // this lane's 16 bytes inside a pass
+    const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
+    auto to_lds = [](const float* src, const float* lds_wave_base) {
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src), "s"((uint32_t)(uintptr_t)lds_wave_base) : "memory");
+    };
     auto stage = [&](int chunk, int buf) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             int t = chunk * GD_T + p * ROWS_PER_PASS + r_in_pass;
             t = t < L ? t : L - 1;
             const int64_t off = (int64_t)t * row_stride + col;
-            const int dst = (p * ROWS_PER_PASS * HD + wave * 256) * 4;     // wave base; lanes land 16 bytes apart
-            glds16(kb + off, (char*)&ks[buf][0][0] + dst);
-            glds16(qb + off, (char*)&qs[buf][0][0] + dst);
-            glds16(vb + off, (char*)&vs[buf][0][0] + dst);
+            const int dst = p * ROWS_PER_PASS * HD + wave * 256;     // wave base; lanes land 16 bytes apart
+            to_lds(kb + off, &ks[buf][0][0] + dst);
+            to_lds(qb + off, &qs[buf][0][0] + dst);
+            to_lds(vb + off, &vs[buf][0][0] + dst);
         }
         if (i < 2 * GD_T) {
             const int which = i / GD_T, tt = i % GD_T;
@@ -72,6 +111,12 @@ __global__ __launch_bounds__(HD) void gated_delta_kernel(const float* __restrict
             t = t < L ? t : L - 1;
             ab[buf][which][tt] = ab_src[which][(int64_t)t * H];
         }
+    };
+
+    // what a step needs before its first instruction: k and the three scalars (q is read inside the step)
+    struct Operands {
+        f32x4_t k[NJ];
+        float a, bt, v;
     };
 
     const int chunks = (L + GD_T - 1) / GD_T;
@@ -82,38 +127,110 @@ __global__ __launch_bounds__(HD) void gated_delta_kernel(const float* __restrict
         __syncthreads();                       // chunk c is in LDS; everybody is done with chunk c-1
         if (c + 1 < chunks) stage(c + 1, buf ^ 1);
         const int steps = (L - c * GD_T) < GD_T ? (L - c * GD_T) : GD_T;
-        for (int t = 0; t < steps; ++t) {
-            const float a = ab[buf][0][t], bt = ab[buf][1][t];
-            const float vi = vs[buf][t][i];
-            f32x2_t kk[HD / 2];
-            f32x2_t acc[2] = {(f32x2_t){0.f, 0.f}, (f32x2_t){0.f, 0.f}};
+        auto load = [&](Operands& x, int t) {
+            x.a = ab[buf][0][t];
+            x.bt = ab[buf][1][t];
+            x.v = vs[buf][t][own];
 #pragma unroll
-            for (int j = 0; j < HD; j += 4) {
-                const f32x4_t k4 = *(const f32x4_t*)&ks[buf][t][j];
-                kk[j / 2] = (f32x2_t){k4[0], k4[1]};
-                kk[j / 2 + 1] = (f32x2_t){k4[2], k4[3]};
-                acc[0] = S[j / 2] * kk[j / 2] + acc[0];
-                acc[1] = S[j / 2 + 1] * kk[j / 2 + 1] + acc[1];
-            }
-            const float sk = (acc[0][0] + acc[0][1]) + (acc[1][0] + acc[1][1]);
-            const float cu = bt * (vi - a * sk);
-            const f32x2_t cu2 = {cu, cu}, a2 = {a, a};
-            f32x2_t oc[2] = {(f32x2_t){0.f, 0.f}, (f32x2_t){0.f, 0.f}};
+            for (int j = 0; j < NJ; ++j) x.k[j] = *(const f32x4_t*)&ks[buf][t][16 * j + 4 * cg];
+        };
+        // One step on operands x, reading those of the next step into y half-way (its q at the start: both reads
+        // have a phase of arithmetic to land in).  FOLDED: the registers hold T = S / gam, gam the running product of
+        // the chunk's decays (the same number in every lane), so alpha * S costs nothing -- gam absorbs it -- and the
+        // rank-1 update is one fma per element, T += (cu / gam') k.  Otherwise the registers hold S itself and the
+        // update is a S + cu k.
+        auto step = [&](auto folded, const Operands& x, Operands& y, int t, float& gam) {
+            constexpr bool FOLDED = decltype(folded)::value;
+            f32x4_t q[NJ];
 #pragma unroll
-            for (int j = 0; j < HD; j += 4) {
-                const f32x4_t q4 = *(const f32x4_t*)&qs[buf][t][j];
-                S[j / 2] = cu2 * kk[j / 2] + a2 * S[j / 2];
-                S[j / 2 + 1] = cu2 * kk[j / 2 + 1] + a2 * S[j / 2 + 1];
-                oc[0] = S[j / 2] * (f32x2_t){q4[0], q4[1]} + oc[0];
-                oc[1] = S[j / 2 + 1] * (f32x2_t){q4[2], q4[3]} + oc[1];
+            for (int j = 0; j < NJ; ++j) q[j] = *(const f32x4_t*)&qs[buf][t][16 * j + 4 * cg];
+            __builtin_amdgcn_sched_barrier(0);
+            const float a = x.a;
+            f32x2_t acc[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[r] = (f32x2_t){0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x2_t ka = {x.k[j][0], x.k[j][1]}, kb2 = {x.k[j][2], x.k[j][3]};
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    acc[r] = T[r][2 * j] * ka + acc[r];
+                    acc[r] = T[r][2 * j + 1] * kb2 + acc[r];
+                }
             }
-            OUT[((int64_t)b * L + c * GD_T + t) * row_stride + h * HD + i] = (oc[0][0] + oc[0][1]) + (oc[1][0] + oc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < steps) load(y, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            float sk = quad_reduce_pairs(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], hi2);        // (S k)[own]
+            if (FOLDED) sk *= gam;
+            float cu = x.bt * (x.v - a * sk);
+            if (FOLDED) {
+                gam *= a;
+                cu *= __builtin_amdgcn_rcpf(gam);
+            }
+            const float cr[2] = {quad_lane<0x00>(cu), quad_lane<0xAA>(cu)};
+            const f32x2_t a2 = {a, a};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[r] = (f32x2_t){0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x2_t ka = {x.k[j][0], x.k[j][1]}, kb2 = {x.k[j][2], x.k[j][3]};
+                const f32x2_t qa = {q[j][0], q[j][1]}, qb2 = {q[j][2], q[j][3]};
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const f32x2_t c2 = {cr[r], cr[r]};
+                    if (FOLDED) {
+                        T[r][2 * j] = c2 * ka + T[r][2 * j];
+                        T[r][2 * j + 1] = c2 * kb2 + T[r][2 * j + 1];
+                    } else {
+                        T[r][2 * j] = c2 * ka + a2 * T[r][2 * j];
+                        T[r][2 * j + 1] = c2 * kb2 + a2 * T[r][2 * j + 1];
+                    }
+                    acc[r] = T[r][2 * j] * qa + acc[r];
+                    acc[r] = T[r][2 * j + 1] * qb2 + acc[r];
+                }
+            }
+            float o = quad_reduce_pairs(acc[0][0] + acc[0][1], acc[1][0] + acc[1][1], hi2);
+            if (FOLDED) o *= gam;
+            if ((cg & 1) == 0) OUT[((int64_t)b * L + c * GD_T + t) * row_stride + h * HD + own] = o;
+        };
+        auto run = [&](auto folded, float& gam) {
+            Operands x0, x1;
+            load(x0, 0);
+            for (int t = 0; t < steps; t += 2) {
+                step(folded, x0, x1, t, gam);
+                if (t + 1 < steps) step(folded, x1, x0, t + 1, gam);
+            }
+        };
+        // A chunk runs folded when the product of its decays stays far inside the float range (then no decay is
+        // zero either); gam goes back into the registers at the end of the chunk.
+        float prod = 1.0f;
+#pragma unroll
+        for (int t4 = 0; t4 < GD_T; t4 += 4) {
+            const f32x4_t a4 = *(const f32x4_t*)&ab[buf][0][t4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) prod *= (t4 + e < steps) ? a4[e] : 1.0f;
+        }
+        if (prod > 1e-20f) {
+            float gam = 1.0f;
+            run(flag<true>{}, gam);
+            const f32x2_t g2 = {gam, gam};
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 2 * NJ; ++j) T[r][j] = g2 * T[r][j];
+        } else {
+            float unused = 1.0f;
+            run(flag<false>{}, unused);
         }
     }
-    float* dst = STATE_OUT + ((int64_t)bh * HD + i) * HD;
 #pragma unroll
-    for (int j = 0; j < HD; j += 4)
-        *(f32x4_t*)(dst + j) = (f32x4_t){S[j / 2][0], S[j / 2][1], S[j / 2 + 1][0], S[j / 2 + 1][1]};
+    for (int r = 0; r < 2; ++r) {
+        float* dst = STATE_OUT + ((int64_t)bh * HD + row0 + r) * HD + 4 * cg;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            *(f32x4_t*)(dst + 16 * j) = (f32x4_t){T[r][2 * j][0], T[r][2 * j][1], T[r][2 * j + 1][0], T[r][2 * j + 1][1]};
+    }
 }
 
 // One wave per (batch, time) row of C channels; lane owns channels 4*lane + 256*m.
@@ -253,10 +370,10 @@ extern "C" int va_gated_delta_seq(const float* q, const float* k, const float* v
     VA_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)state_out | (uintptr_t)state_in) % 16 == 0,
                  "va_gated_delta_seq: misaligned operand");
     if (hd == 128)
-        hipLaunchKernelGGL(gated_delta_kernel<128>, dim3((unsigned)(B * H)), dim3(128), 0, stream, q, k, v, alpha, beta,
+        hipLaunchKernelGGL(gated_delta_kernel<128>, dim3((unsigned)(B * H)), dim3(256), 0, stream, q, k, v, alpha, beta,
                            state_in, out, state_out, (int)L, (int)H);
     else
-        hipLaunchKernelGGL(gated_delta_kernel<64>, dim3((unsigned)(B * H)), dim3(64), 0, stream, q, k, v, alpha, beta,
+        hipLaunchKernelGGL(gated_delta_kernel<64>, dim3((unsigned)(B * H)), dim3(128), 0, stream, q, k, v, alpha, beta,
                            state_in, out, state_out, (int)L, (int)H);
     VA_CHECK_LAUNCH("va_gated_delta_seq");
     return VA_OK;
