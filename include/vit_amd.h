@@ -268,6 +268,12 @@ int va_gated_delta_seq(const float* q, const float* k, const float* v, const flo
 int va_dwconv1d_causal_silu(const float* x, const float* w, const float* bias, float* out, int64_t B, int64_t L,
                             int64_t C, int normalize, va_stream_t stream);
 
+/* Output stage of the layer between the recurrence and the output projection (swm:511-519):
+ * y = LayerNorm((o * gate) * silu(g); gamma, beta, eps) as bf16.  o (the recurrence output), gate (the second half
+ * of the convolved v projection, swm:500) and g (the raw g_proj output, swm:515): f32 [M, D] contiguous; D = 1024. */
+int va_gate_layernorm_fwd(const float* o, const float* gate, const float* g, const float* gamma, const float* beta,
+                          void* y_bf16, int64_t M, int64_t D, float eps, va_stream_t stream);
+
 /* ---- input pipeline: the tensor side of the reference's per-frame transform (ToTensor + Normalize,
  * stage1_surgvu_pretraining.py:241-244, 279-286) ---------------------------------------------------------
  * frames: uint8 [B, T, H, W, 3] on the device -> out: f32 [B, 3, T, H, W], (u / 255 - mean[c]) / std[c]

@@ -117,6 +117,26 @@ def test_gated_delta_long_sequence_stays_close(env):
     assert (st.cpu() - ref_s).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize("M", [1, 5, 1030])
+def test_gate_layernorm_vs_torch(env, M):
+    """LayerNorm((o * gate) * silu(g)) in one pass (swm:511-519) against the torch f32 formulation; bf16 output."""
+    ops, _ = env
+    F = torch.nn.functional
+    o = R.hashed_uniform("t.gl.o", (M, 1024), 2.0).cuda()
+    gate = R.hashed_uniform("t.gl.gate", (M, 1024), 1.5).cuda()
+    g = R.hashed_uniform("t.gl.g", (M, 1024), 4.0).cuda()
+    gamma = R.hashed_uniform("t.gl.gamma", (1024,), 0.5, 1.0).cuda()
+    beta = R.hashed_uniform("t.gl.beta", (1024,), 0.3).cuda()
+    out = torch.empty(M, 1024, dtype=torch.bfloat16, device="cuda")
+    ops.gate_layernorm_fwd(o, gate, g, gamma, beta, out, 1e-5)
+    ref = F.layer_norm((o * gate) * F.silu(g), (1024,), gamma, beta, 1e-5)
+    assert (out.float() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6      # bf16 rounding
+    assert (out.float() - ref.bfloat16().float()).abs().gt(0).float().mean().item() < 0.01             # and mostly the same bits
+    with pytest.raises(Exception):
+        ops.gate_layernorm_fwd(o[:, :512].contiguous(), gate[:, :512].contiguous(), g[:, :512].contiguous(), gamma[:512],
+                               beta[:512], out[:, :512].contiguous(), 1e-5)
+
+
 @pytest.mark.parametrize("B,L,C,norm", [(2, 1, 1024, True), (2, 7, 1024, True), (3, 50, 2048, False), (1, 5, 256, True)])
 def test_dwconv_silu_vs_oracle(env, B, L, C, norm):
     ops, _ = env

@@ -68,6 +68,7 @@ SIGNATURES = {
     "va_multi_adamw": (ci, [vp, vp, i64, cf, cf, cf, cf, cf, vp, cf, vp]),
     "va_gated_delta_seq": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "va_dwconv1d_causal_silu": (ci, [vp, vp, vp, vp, i64, i64, i64, ci, vp]),
+    "va_gate_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, i64, i64, cf, vp]),
 }
 
 

@@ -13,6 +13,7 @@
 //    goes back to the quad with two quad broadcasts, and one of them writes the row's output.  k/q/v/alpha/beta
 //    of 16 steps at a time are staged in LDS (double-buffered; fetched into registers a chunk ahead), and a step's
 //    operands are read from LDS while the step before it computes.
+//  * gate_ln_kernel: the layer's output stage, (o * gate) * silu(g) then LayerNorm (swm:511-519), as one pass.
 //  * dwconv_silu_kernel: causal depthwise conv1d (4 taps, swm:452-457 with the [..., :L] cut of swm:484-486)
 //    + bias + SiLU, optionally followed by the row-wise L2 normalisation of swm:489-490.
 #include "common.h"
@@ -358,6 +359,55 @@ void launch_dwconv_run(const float* x, const float* w, const float* bias, float*
                        bias, out, runs, L, normalize);
 }
 
+// Output stage of the memory layer (swm:511-519 up to the projection): row = (o * gate) * silu(g), then
+// LayerNorm over the 1024-wide row, written as the bf16 operand of the output projection.  One wave per row,
+// 16 elements per lane.
+constexpr int GLN_D = 1024;
+__global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ o, const float* __restrict__ gate,
+                                                      const float* __restrict__ g, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ y, int64_t M,
+                                                      float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4_t v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t at = row * GLN_D + q * 256 + lane * 4;
+        const f32x4_t ov = *(const f32x4_t*)(o + at), gv = *(const f32x4_t*)(gate + at), xv = *(const f32x4_t*)(g + at);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float silu = xv[j] / (1.0f + __expf(-xv[j]));
+            v[q][j] = (ov[j] * gv[j]) * silu;
+            s += v[q][j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mu = s * (1.0f / GLN_D);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[q][j] - mu;
+            ss += d * d;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rs = rsqrtf(ss * (1.0f / GLN_D) + eps);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = q * 256 + lane * 4;
+        const f32x4_t gm = *(const f32x4_t*)(gamma + c), bt = *(const f32x4_t*)(beta + c);
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = (v[q][j] - mu) * rs * gm[j] + bt[j];
+        *(u32x2_t*)(y + row * GLN_D + c) = (u32x2_t){pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+    }
+}
+
 }  // namespace
 
 extern "C" int va_gated_delta_seq(const float* q, const float* k, const float* v, const float* alpha, const float* beta,
@@ -399,5 +449,18 @@ extern "C" int va_dwconv1d_causal_silu(const float* x, const float* w, const flo
                                rows, (int)L, (int)C, normalize);
     }
     VA_CHECK_LAUNCH("va_dwconv1d_causal_silu");
+    return VA_OK;
+}
+
+extern "C" int va_gate_layernorm_fwd(const float* o, const float* gate, const float* g, const float* gamma,
+                                     const float* beta, void* y_bf16, int64_t M, int64_t D, float eps, hipStream_t stream) {
+    VA_CHECK_ARG(o && gate && g && gamma && beta && y_bf16, "va_gate_layernorm_fwd: null operand");
+    VA_CHECK_ARG(D == GLN_D, "va_gate_layernorm_fwd: width %lld not supported (1024)", (long long)D);
+    VA_CHECK_ARG(M > 0 && M < (1ll << 33), "va_gate_layernorm_fwd: row count out of range");
+    VA_CHECK_ARG(((uintptr_t)o | (uintptr_t)gate | (uintptr_t)g | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y_bf16) % 16 == 0,
+                 "va_gate_layernorm_fwd: misaligned operand");
+    hipLaunchKernelGGL(gate_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, o, gate, g, gamma, beta,
+                       (bf16_t*)y_bf16, M, eps);
+    VA_CHECK_LAUNCH("va_gate_layernorm_fwd");
     return VA_OK;
 }

@@ -414,6 +414,21 @@ def dwconv1d_causal_silu(x, weight, bias, normalize: bool):
     return out
 
 
+def gate_layernorm_fwd(o, gate, g, gamma, beta, out, eps: float = 1e-5):
+    """out (bf16 [M,D]) = LayerNorm((o * gate) * silu(g)); o, gate, g f32 [M,D] contiguous (swm:511-519)."""
+    M, D = o.shape
+    for name, x in (("o", o), ("gate", gate), ("g", g)):
+        _need(x, F32, name)
+        if tuple(x.shape) != (M, D) or not x.is_contiguous():
+            raise ValueError(f"gate_layernorm_fwd: {name} must be contiguous [M,D]")
+    _need(gamma, F32, "gamma"); _need(beta, F32, "beta"); _need(out, BF16, "out")
+    if tuple(out.shape) != (M, D) or not out.is_contiguous() or gamma.numel() != D or beta.numel() != D:
+        raise ValueError("gate_layernorm_fwd: inconsistent shapes")
+    check(_lib.load().va_gate_layernorm_fwd(_p(o), _p(gate), _p(g), _p(gamma), _p(beta), _p(out), M, D, eps, _stream()),
+          "va_gate_layernorm_fwd")
+    return out
+
+
 # ------------------------------------------------------------------ casts
 def cast_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
     _need(src, F32, "src")

@@ -1,10 +1,10 @@
 """Inference launch schedule of one predictor block (HybridPredictorBlock.forward, swm:975-997) on the HIP
 kernels: LayerNorm -> in-proj GEMM (+bias) -> block-causal attention -> out-proj GEMM (+bias +residual) ->
-[gated delta memory: projection GEMMs, causal conv + SiLU (+normalise), delta-rule recurrence, gating,
+[gated delta memory: projection GEMMs, causal conv + SiLU (+normalise), delta-rule recurrence, gating +
 LayerNorm, o-proj GEMM (+residual)] -> LayerNorm -> fc1 (+bias, GELU) -> fc2 (+bias +residual).
 
 Same numeric scheme as the encoder: f32 residual stream and statistics, bf16 GEMM/attention operands with f32
-accumulation.  The two 8-wide gate projections (a_proj, b_proj) and the elementwise gating stay torch ops.
+accumulation.  The two 8-wide gate projections (a_proj, b_proj) stay a torch product.
 """
 from __future__ import annotations
 
@@ -61,23 +61,29 @@ def block_forward(blk, x: torch.Tensor, tokens_per_timestep: int, state: Optiona
         Hd, Dh = t.num_heads, t.head_dim
         inner = Hd * Dh
         xb = ops.cast_bf16(x_mid)
+        # v_proj's two halves (the value and its gate, swm:500) as two GEMMs and two convolutions, so that each half
+        # is a contiguous operand of the kernels that follow
+        wv = wc.fwd("v_proj", t.v_proj.weight)
+        conv_w, conv_b = t.v_conv1d.weight.detach().reshape(2 * inner, 4), t.v_conv1d.bias.detach()
         lin = {}
-        for name, cols in (("q", inner), ("k", inner), ("v", 2 * inner), ("g", inner)):
-            lin[name] = new(cols, F32)
-            ops.gemm_nt(xb, wc.fwd(name + "_proj", getattr(t, name + "_proj").weight), ops.EPI_F32, lin[name])
-        alpha = torch.sigmoid(x_mid @ t.a_proj.weight.detach().t()).view(B, L, Hd)
-        beta = torch.sigmoid(x_mid @ t.b_proj.weight.detach().t()).view(B, L, Hd)
+        for name, w in (("q", wc.fwd("q_proj", t.q_proj.weight)), ("k", wc.fwd("k_proj", t.k_proj.weight)),
+                        ("v", wv[:inner]), ("gate", wv[inner:]), ("g", wc.fwd("g_proj", t.g_proj.weight))):
+            lin[name] = new(inner, F32)
+            ops.gemm_nt(xb, w, ops.EPI_F32, lin[name])
+        # the two 8-wide gate projections as one product
+        ab = torch.sigmoid(x_mid @ torch.cat([t.a_proj.weight.detach(), t.b_proj.weight.detach()]).t())
+        alpha, beta = ab[:, :Hd].contiguous().view(B, L, Hd), ab[:, Hd:].contiguous().view(B, L, Hd)
         q = ops.dwconv1d_causal_silu(lin["q"].view(B, L, inner), t.q_conv1d.weight.detach(), t.q_conv1d.bias.detach(), True)
         k = ops.dwconv1d_causal_silu(lin["k"].view(B, L, inner), t.k_conv1d.weight.detach(), t.k_conv1d.bias.detach(), True)
-        v = ops.dwconv1d_causal_silu(lin["v"].view(B, L, 2 * inner), t.v_conv1d.weight.detach(), t.v_conv1d.bias.detach(), False)
-        v, v_gate = v[..., :inner].contiguous(), v[..., inner:]
-        out, new_state = ops.gated_delta_seq(q.view(B, L, Hd, Dh), k.view(B, L, Hd, Dh), v.view(B, L, Hd, Dh),
-                                             alpha.contiguous(), beta.contiguous(),
+        v = ops.dwconv1d_causal_silu(lin["v"].view(B, L, inner), conv_w[:inner], conv_b[:inner], False)
+        v_gate = ops.dwconv1d_causal_silu(lin["gate"].view(B, L, inner), conv_w[inner:], conv_b[inner:], False)
+        out, new_state = ops.gated_delta_seq(q.view(B, L, Hd, Dh), k.view(B, L, Hd, Dh), v.view(B, L, Hd, Dh), alpha, beta,
                                              None if state is None else state.detach().contiguous())
-        gated = (out.view(B, L, inner) * v_gate * F.silu(lin["g"].view(B, L, inner))).reshape(M, inner)
-        del lin, q, k, v, out
+        del q, k, v
         on = new(inner, BF16)
-        ops.layernorm_fwd(gated, t.o_norm.weight, t.o_norm.bias, on, mean, rstd, t.o_norm.eps)
+        ops.gate_layernorm_fwd(out.view(M, inner), v_gate.view(M, inner), lin["g"], t.o_norm.weight.detach(),
+                               t.o_norm.bias.detach(), on, t.o_norm.eps)
+        del lin, out, v_gate
         x_dn = new(D, F32)
         ops.gemm_nt(on, wc.fwd("o_proj", t.o_proj.weight), ops.EPI_F32, x_dn, resid=x_mid)
         x_mid = x_dn
