@@ -1,62 +1,77 @@
-// Issue rate of f32 fused multiply-adds on one SIMD: single v_fma_f32 against v_pk_fma_f32, with 1, 2 or 4 waves
-// per SIMD.  Each wave runs ITER rounds of 16 independent accumulators (so no dependent-chain stall), and the
-// kernel is timed with s_memtime.  Prints cycles per instruction per SIMD.
+// Micro-benchmark: issue rate of the integer VALU ops a counter-based mask hash can be built from
+// (32-bit multiply, 24-bit multiply / multiply-add, xor, shift-add), 8 independent chains per lane, 8 waves per CU.
+// Build: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <cstdlib>
 
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-constexpr int ITER = 4096;
-
-template <int KIND>
-__global__ __launch_bounds__(1024) void rate_kernel(float* out, long long* cycles, float a, float b) {
-    float acc[16];
-    f32x2_t pacc[16];
+template <int OP>
+__global__ __launch_bounds__(512) void k(uint32_t* __restrict__ out, uint32_t seed, int iters) {
+    uint32_t x[8];
+    for (int i = 0; i < 8; ++i) x[i] = seed + threadIdx.x * 9 + i;
+    uint32_t c = seed | 1;
+    for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i] = (float)(threadIdx.x + i); pacc[i] = (f32x2_t){acc[i], acc[i] + 1.f}; }
-    const f32x2_t a2 = {a, a}, b2 = {b, b};
-    __syncthreads();
-    const long long t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < ITER; ++it) {
+        for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (KIND == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
-            if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pacc[i]) : "v"(a2), "v"(b2));
-            if (KIND == 2) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
-            if (KIND == 3) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(pacc[i]) : "v"(a2));
-        }
+            for (int i = 0; i < 8; ++i) {
+                if (OP == 0) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+                if (OP == 1) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+                if (OP == 2) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(x[i]) : "v"(c));
+                if (OP == 3) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+                if (OP == 4) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x[i]) : "v"(c));
+                if (OP == 5) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+                if (OP == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+                if (OP == 7) asm volatile("v_xad_u32 %0, %0, %1, %0" : "+v"(x[i]) : "v"(c));
+                if (OP == 8) asm volatile("v_lshrrev_b32 %0, 15, %0" : "+v"(x[i]));
+                if (OP == 10) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[i]) : "v"(c));
+                if (OP == 11) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+                if (OP == 12) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
+                if (OP == 13 && (i & 1) == 0) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(*(uint64_t*)&x[i]) : "v"(*(uint64_t*)&x[0]));
+                if (OP == 14 && (i & 1) == 0) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(uint64_t*)&x[i]) : "v"(*(uint64_t*)&x[0]));
+                if (OP == 15) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(c) : "vcc");
+                if (OP == 16) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+                if (OP == 9) asm volatile("v_cmp_ge_u16_sdwa vcc, %0, %1 src0_sel:WORD_1 src1_sel:WORD_0\n v_cndmask_b32 %0, 0, %0, vcc" : "+v"(x[i]) : "v"(c) : "vcc");
+            }
     }
-    const long long t1 = __builtin_readcyclecounter();
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += acc[i] + pacc[i][0] + pacc[i][1];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+    uint32_t s = 0;
+    for (int i = 0; i < 8; ++i) s ^= x[i];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <int OP>
+void run(const char* name, uint32_t* out, int per) {
+    const int blocks = 256, iters = 4000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(512), 0, 0, out, 12345u, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    // wave-instructions per SIMD: 2 waves per SIMD x iters x 64 x per
+    const double winst = 2.0 * iters * 64 * per;
+    printf("%-28s %.3f ms   %.2f ns per wave-instruction per SIMD\n", name, ms, ms * 1e6 / winst);
 }
 
 int main() {
-    float* out; long long* cyc;
-    if (hipMalloc(&out, 1024 * 256 * 4) != hipSuccess || hipMalloc(&cyc, 256 * 8) != hipSuccess) return 1;
-    const char* names[4] = {"v_fma_f32", "v_pk_fma_f32", "v_fmac_f32", "v_pk_mul_f32"};
-    for (int kind = 0; kind < 4; ++kind)
-        for (int waves_per_simd : {1, 2, 4}) {
-            const int threads = 256 * waves_per_simd;       // one workgroup on one CU: waves spread over the 4 SIMDs
-            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            for (int rep = 0; rep < 2; ++rep) {
-                hipEventRecord(e0);
-                if (kind == 0) hipLaunchKernelGGL(rate_kernel<0>, dim3(1), dim3(threads), 0, 0, out, cyc, 1.0001f, 0.5f);
-                if (kind == 1) hipLaunchKernelGGL(rate_kernel<1>, dim3(1), dim3(threads), 0, 0, out, cyc, 1.0001f, 0.5f);
-                if (kind == 2) hipLaunchKernelGGL(rate_kernel<2>, dim3(1), dim3(threads), 0, 0, out, cyc, 1.0001f, 0.5f);
-                if (kind == 3) hipLaunchKernelGGL(rate_kernel<3>, dim3(1), dim3(threads), 0, 0, out, cyc, 1.0001f, 0.5f);
-                hipEventRecord(e1);
-                if (hipEventSynchronize(e1) != hipSuccess) { printf("launch failed\n"); return 1; }
-            }
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-            const double per_simd_instr = (double)ITER * 16 * waves_per_simd;
-            printf("%-14s %d wave(s)/SIMD: %8lld counter ticks, %.3f ms -> %.2f ns per instruction per SIMD\n", names[kind],
-                   waves_per_simd, c, ms, ms * 1e6 / per_simd_instr);
-        }
+    uint32_t* out; hipMalloc(&out, 256 * 512 * 4);
+    run<3>("v_xor_b32", out, 1);
+    run<0>("v_mul_lo_u32", out, 1);
+    run<5>("v_mul_hi_u32", out, 1);
+    run<1>("v_mul_u32_u24", out, 1);
+    run<2>("v_mad_u32_u24", out, 1);
+    run<4>("v_lshl_add_u32", out, 1);
+    run<7>("v_xad_u32", out, 1);
+    run<8>("v_lshrrev_b32", out, 1);
+    run<6>("v_exp_f32", out, 1);
+    run<9>("v_cmp_u16_sdwa+v_cndmask", out, 2);
+    run<10>("v_fma_f32", out, 1);
+    run<11>("v_mul_f32", out, 1);
+    run<12>("v_rcp_f32", out, 1);
+    run<13>("v_pk_fma_f32 (per instr, 2 elems; half as many issued)", out, 1);
+    run<14>("v_pk_mul_f32 (per instr, 2 elems; half as many issued)", out, 1);
+    run<15>("v_cndmask_b32", out, 1);
+    run<16>("v_cvt_pk_bf16_f32", out, 1);
     return 0;
 }
