@@ -88,11 +88,12 @@ __global__ __launch_bounds__(2 * HD) __attribute__((amdgpu_waves_per_eu(2))) voi
     // Staging of a chunk: direct-to-LDS loads issued at the start of the previous chunk and waited for at its end.
     // They are written as assembly because the compiler, not knowing which LDS bytes such a load writes, would
     // otherwise drain the vector-memory counter before every LDS read of the step loop.  (m0 holds nothing of the
-    // compiler's between statements in this kernel: it sets it only for instructions of this kind.)
+    // compiler's between statements in this kernel: it sets it only for instructions of this kind.  The s_nop is the
+    // wait state between a scalar write of m0 and an instruction that reads it.)
     const int r_in_pass = i * 4 / HD, col = (i * 4) % HD;     // this lane's 16 bytes inside a pass
     const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
     auto to_lds = [](const float* src, const float* lds_wave_base) {
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                      :: "v"(src), "s"((uint32_t)(uintptr_t)lds_wave_base) : "memory");
     };
     auto stage = [&](int chunk, int buf) {
