@@ -197,6 +197,30 @@ def test_predictor_block_matches_reference_vectors(env, gold):
         assert rel(y2.detach(), y) < REL_TOL
 
 
+@pytest.mark.parametrize("heads", [16, 8])
+def test_predictor_block_kernel_path_equals_torch_formulation(env, heads):
+    """A block with 16 heads (head dim 64 in the attention and in the recurrence) and with 8 (head dim 128), on a
+    sequence of 5 steps x 33 tokens that is not a multiple of any tile: the inference path on the kernels against
+    the module's own torch formulation (the one autograd uses), outputs and recurrence state, also with a state
+    carried in from a previous call."""
+    _, swm = env
+    dim, tpt, T = 1024, 33, 5
+    L = tpt * T
+    x = R.hashed_uniform("t.pb16.x", (2, L, dim), 1.0).cuda()
+    mask = swm.BlockCausalMask.create_mask(L, tpt, x.device)
+    blk = swm.HybridPredictorBlock(dim, heads, use_deltanet=True).eval()
+    P = R.fill_state_dict_({"pb." + k: v for k, v in blk.state_dict().items()})
+    blk.load_state_dict({k[3:]: v for k, v in P.items()})
+    blk = blk.cuda()
+    with torch.no_grad():
+        y, st = blk(x, attn_mask=mask)
+        y_next, st_next = blk(y, attn_mask=mask, state=st)
+    y_t, st_t = blk(x.clone().requires_grad_(True), attn_mask=mask)
+    assert rel(y, y_t.detach()) < REL_TOL and rel(st, st_t.detach()) < REL_TOL
+    y_t2, st_t2 = blk(y.clone().requires_grad_(True), attn_mask=mask, state=st)
+    assert rel(y_next, y_t2.detach()) < REL_TOL and rel(st_next, st_t2.detach()) < REL_TOL
+
+
 def test_world_model_forward_matches_reference_vectors(env, gold):
     _, swm = env
     torch.manual_seed(0)
