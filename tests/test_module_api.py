@@ -122,12 +122,83 @@ def test_predictor_pieces_on_cpu():
     assert y.shape == (B, L, 64) and st.shape == (B, 2, 32, 32)
 
 
-def test_unchanged_import_resolves_to_the_drop_in(golden_dir):
-    """The reference's scripts do `from surgical_world_model import SurgicalActionConditionedWorldModel`
-    (stage1_surgvu_pretraining.py:26, stage1_vjepa2_finetuning.py:40) and `... import ..., VideoViTEncoder`
-    (load_vjepa2_pretrained.py:23).  A child interpreter with only `dropin/` in front of the path must resolve
-    those imports to this package and build an encoder with the reference's state-dict keys."""
+_IMPORT_FORMS = (
+    "from surgical_world_model import SurgicalActionConditionedWorldModel",                     # s1:26, ft:40
+    "from surgical_world_model import SurgicalActionConditionedWorldModel, VideoViTEncoder",    # lp:23
+    "import surgical_world_model",
+)
+
+
+def _reference_layout(tmp_path):
+    """A directory laid out like the reference's: a script next to a `surgical_world_model.py` of its own (a decoy
+    here) and a sibling module that imports the model too, as stage1_vjepa2_finetuning.py imports
+    stage1_surgvu_pretraining.py."""
+    (tmp_path / "surgical_world_model.py").write_text(
+        "class SurgicalActionConditionedWorldModel: pass\nclass VideoViTEncoder: pass\nDECOY = True\n")
+    (tmp_path / "sibling_stage1.py").write_text(
+        "from surgical_world_model import SurgicalActionConditionedWorldModel as SiblingModel\n")
+    script = tmp_path / "train_script.py"
+    script.write_text(
+        "import json, os, sys\n" + "\n".join(_IMPORT_FORMS) + "\n"
+        "from sibling_stage1 import SiblingModel\n"
+        "print(json.dumps({'cls': SurgicalActionConditionedWorldModel.__module__, 'enc': VideoViTEncoder.__module__,\n"
+        "                  'sibling': SiblingModel.__module__, 'file': surgical_world_model.__file__,\n"
+        "                  'decoy': hasattr(surgical_world_model, 'DECOY'), 'argv': sys.argv[1:], 'name': __name__,\n"
+        "                  'path0': sys.path[0], 'all': sorted(getattr(surgical_world_model, '__all__', []))}))\n")
+    return script
+
+
+def _child(cmd, env_extra, cwd):
+    import json
     import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env.update(env_extra)
+    out = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_launcher_runs_an_unchanged_script_on_the_drop_in(tmp_path):
+    """`python -m vit_amd.run script.py args` — the documented way to run the reference's scripts unchanged — must
+    resolve every import form of the scripts (stage1_surgvu_pretraining.py:26, stage1_vjepa2_finetuning.py:40,
+    load_vjepa2_pretrained.py:23), also from a sibling module, to this package although a `surgical_world_model.py`
+    lies next to the script, and must hand the script its arguments, `__main__` and its own directory on the path."""
+    import sys
+    script = _reference_layout(tmp_path)
+    info = _child([sys.executable, "-m", "vit_amd.run", str(script), "--epochs", "3"], {"PYTHONPATH": ROOT}, cwd="/")
+    assert info["cls"] == info["enc"] == info["sibling"] == "vit_amd.surgical_world_model"
+    assert info["file"] == os.path.join(ROOT, "vit_amd", "surgical_world_model.py") and not info["decoy"]
+    assert info["argv"] == ["--epochs", "3"] and info["name"] == "__main__" and info["path0"] == str(tmp_path)
+    for name in ("rotate_half", "apply_rotary_pos_emb", "TubeletEmbedding", "VideoRoPE3D", "RoPEMultiheadAttention",
+                 "GatedDeltaLayer", "VideoViTBlock", "VideoViTEncoder", "ActionStateEmbedding", "HybridPredictorBlock",
+                 "BlockCausalMask", "SpatialAttentionPooling", "AutoregressivePredictor", "DualSterilityClassifier",
+                 "SurgicalActionConditionedWorldModel"):
+        assert name in info["all"], name
+
+
+def test_a_path_entry_alone_does_not_win_over_the_script_directory(tmp_path):
+    """Why the launcher exists: with only `dropin/` on PYTHONPATH a script launched as a file still gets the
+    `surgical_world_model.py` that lies next to it (the script's directory is searched first).  The documentation must
+    never go back to recommending that for scripts inside the reference's directory."""
+    import sys
+    script = _reference_layout(tmp_path)
+    info = _child([sys.executable, str(script)], {"PYTHONPATH": os.path.join(ROOT, "dropin")}, cwd="/")
+    assert info["decoy"] and info["cls"] == "surgical_world_model"
+
+
+def test_launcher_rejects_a_missing_script():
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env["PYTHONPATH"] = ROOT
+    out = subprocess.run([sys.executable, "-m", "vit_amd.run", "/nonexistent/script.py"], env=env, cwd="/",
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "no such script" in out.stderr
+
+
+def test_shim_directory_serves_imports_that_have_no_model_file_beside_them(golden_dir):
+    """`dropin/` on the path is enough wherever no `surgical_world_model.py` shadows it: `python -c`, `python -m`, a
+    notebook, or a copy of a script kept outside the reference's directory."""
     import sys
     code = (
         "import sys, json\n"
@@ -137,22 +208,12 @@ def test_unchanged_import_resolves_to_the_drop_in(golden_dir):
         "torch.manual_seed(0)\n"
         "enc = VideoViTEncoder(img_size=32, num_frames=4, embed_dim=1024, depth=1, num_heads=16)\n"
         "print(json.dumps({'file': m.__file__, 'cls': SurgicalActionConditionedWorldModel.__module__,\n"
-        "                  'keys': list(enc.state_dict().keys()), 'all': sorted(m.__all__)}))\n")
-    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
-    env["PYTHONPATH"] = os.path.join(ROOT, "dropin")
-    out = subprocess.run([sys.executable, "-c", code], cwd="/", env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
-    import json
-    info = json.loads(out.stdout.strip().splitlines()[-1])
+        "                  'keys': list(enc.state_dict().keys())}))\n")
+    info = _child([sys.executable, "-c", code], {"PYTHONPATH": os.path.join(ROOT, "dropin")}, cwd="/")
     assert info["file"] == os.path.join(ROOT, "dropin", "surgical_world_model.py")
     assert info["cls"] == "vit_amd.surgical_world_model"
     g = np.load(os.path.join(golden_dir, "seed_canary.npz"), allow_pickle=False)
     assert info["keys"] == [str(k) for k in g["keys"]]
-    for name in ("rotate_half", "apply_rotary_pos_emb", "TubeletEmbedding", "VideoRoPE3D", "RoPEMultiheadAttention",
-                 "GatedDeltaLayer", "VideoViTBlock", "VideoViTEncoder", "ActionStateEmbedding", "HybridPredictorBlock",
-                 "BlockCausalMask", "SpatialAttentionPooling", "AutoregressivePredictor", "DualSterilityClassifier",
-                 "SurgicalActionConditionedWorldModel"):
-        assert name in info["all"], name
 
 
 def test_rotary_helpers_match_their_definition():
