@@ -100,8 +100,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.gpus < 1 or world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: for N > 1 launch one rank per GPU with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {max(args.gpus, 1)} --master-addr 127.0.0.1 "
+                         f"--master-port P bench.py --gpus {max(args.gpus, 1)} ...`")
+    if not (0 <= rank < world and 0 <= local_rank < world):
+        raise SystemExit(f"bench.py: RANK={rank} / LOCAL_RANK={local_rank} outside a world of {world} (one node, one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -122,6 +126,9 @@ def main():
             dist.broadcast(p.data, src=0)
         reducer = BucketReducer()
         enc.set_grad_reducer(reducer)
+        if dist.get_world_size() != world or dist.get_backend() != "nccl":
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks on backend {dist.get_backend()!r}, "
+                             f"expected {world} on 'nccl' (RCCL)")
     video = torch.randn(args.batch, 3, FRAMES, IMG, IMG, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
     n_tokens = (FRAMES // 2) * (IMG // 16) * (IMG // 16)
 
@@ -147,16 +154,30 @@ def main():
 
     fence()
     probe.enabled = True
+    if reducer is not None:
+        reducer.buckets_reduced = reducer.bytes_reduced = 0
+        reducer.measure_exposed = True
+        reducer.exposed_ms()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
+    comm = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        exposed = reducer.exposed_ms()                   # one join per step, after the timed region (it synchronises)
+        t = torch.tensor([elapsed, sum(exposed) / max(len(exposed), 1), max(exposed or [0.0])], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        elapsed = t[0].item()
+        # what the data-parallel exchange was and what it cost, so that a scaling run explains itself
+        comm = {"backend": "nccl (RCCL)", "ranks_in_process_group": dist.get_world_size(),
+                "buckets_per_step": reducer.buckets_reduced // args.steps,
+                "bytes_reduced_per_step": reducer.bytes_reduced // args.steps, "reduce_op": "avg, f32, one bucket per block",
+                "exposed_comm_ms_per_step_max_over_ranks": round(t[1].item(), 3),
+                "exposed_comm_ms_worst_step": round(t[2].item(), 3),
+                "exposed_comm_definition": "device time between the end of the last backward kernel and the end of the last "
+                                           "bucket's all-reduce (HIP events on the compute stream around the join)"}
 
     if rank == 0:
         clips = args.batch * world * args.steps
@@ -191,6 +212,8 @@ def main():
             "loss": float(loss.detach()),
             "roofline": roofline,
         }
+        if comm is not None:
+            out["extra"] = {"data_parallel": comm}
         if world == 1 and not args.no_cpu_baseline:
             enc.eval()                                   # the oracle's arithmetic is the eval-mode one
             with torch.no_grad():

@@ -102,6 +102,35 @@ def test_reducer_is_a_noop_for_one_rank(tmp_path):
         dist.destroy_process_group()
 
 
+def _missing_grad_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a = torch.nn.Parameter(torch.zeros(3))
+        b = torch.nn.Parameter(torch.zeros(2, 2))
+        frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+        a.grad = torch.full((3,), float(rank + 1))
+        if rank == 0:                                    # rank 1 never produced a gradient for `b`
+            b.grad = torch.full((2, 2), 4.0)
+        reducer = BucketReducer()
+        reducer.reduce_gradients([a, b, frozen])
+        assert reducer.buckets_reduced == 1 and reducer.bytes_reduced == (3 + 4) * 4
+        torch.testing.assert_close(a.grad, torch.full((3,), 1.5))
+        torch.testing.assert_close(b.grad, torch.full((2, 2), 2.0))      # (4 + 0) / 2 on BOTH ranks
+        assert frozen.grad is None
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_bucket_has_the_same_size_on_every_rank_when_a_gradient_is_missing(tmp_path):
+    """A parameter without a gradient on one rank (an empty shard, a head that rank did not use) must not change the
+    size of the bucket or skip the collective there: the ranks would disagree and hang.  Zeros stand in."""
+    world = 2
+    mp.spawn(_missing_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the whole stage-1 step (heads, gathered InfoNCE, clip, AdamW) under data parallelism
 # ---------------------------------------------------------------------------------------------------------------

@@ -39,6 +39,47 @@ def test_bucket_reducer_on_rccl_world_of_one():
         dist.destroy_process_group()
 
 
+def test_broadcast_after_a_forward_drops_every_cached_operand_copy():
+    """`broadcast_parameters` writes through `.data`, which does not bump the version counters the bf16 operand
+    caches key on.  A forward that ran BEFORE the broadcast (a warm-up, a re-sync after loading a checkpoint) must
+    not leave stale copies in use: after the broadcast of the whole world model the encoder and the predictor blocks
+    must compute with the new parameters.  World of one: the parameters are rewritten the way a broadcast from
+    another rank rewrites them, then the real broadcast (and its invalidation) runs."""
+    from vit_amd import surgical_world_model as swm
+    from vit_amd.ddp import broadcast_parameters
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        def build(seed):
+            torch.manual_seed(seed)
+            return swm.SurgicalActionConditionedWorldModel(img_size=32, num_frames=4, encoder_depth=1, encoder_heads=16,
+                                                           predictor_depth=2, predictor_heads=8).eval().cuda()
+        model, other = build(1), build(2)
+        video = R.hashed_uniform("ddp.bc.video", (2, 3, 4, 32, 32), 1.0).cuda()
+        actions = R.hashed_uniform("ddp.bc.a", (2, 4, 7), 1.0).cuda()
+        states = R.hashed_uniform("ddp.bc.s", (2, 4, 7), 1.0).cuda()
+
+        def run(m):
+            with torch.no_grad():
+                preds, cur, fut = m(video, actions, states, predict_horizon=1)
+            return torch.cat([m.encode_video(video).flatten(), preds[0]["features"].flatten(), cur.flatten(), fut.flatten()])
+
+        stale = run(model)                                  # fills every operand cache from the seed-1 weights
+        want = run(other)
+        assert not torch.allclose(stale, want)
+        with torch.no_grad():                               # what receiving a broadcast does: raw writes
+            for dst, src in zip(list(model.parameters()) + list(model.buffers()),
+                                list(other.parameters()) + list(other.buffers())):
+                dst.data.copy_(src.data)
+        broadcast_parameters(model)
+        assert torch.equal(run(model), want)
+    finally:
+        dist.destroy_process_group()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the whole stage-1 step with the real encoder on two ranks that share this GPU (gloo: vit_amd.ddp stages device
 # buffers through host memory; RCCL refuses ranks that share a device) against one rank on the concatenated batch

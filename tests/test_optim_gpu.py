@@ -125,3 +125,58 @@ def test_two_param_groups_scheduler_and_state_dict_interchange(tmp_path):
         assert torch.allclose(a, d, rtol=2e-6, atol=2e-7)
         assert torch.allclose(a, e, rtol=2e-6, atol=2e-7)
     assert float(resumed.state[p2[0]]["step"]) == 4.0
+
+
+def test_frozen_parameters_keep_their_place_in_the_state_dict():
+    """A group that holds a `requires_grad=False` parameter (the frozen encoder of the fine-tuning recipe when all
+    parameters are handed over): torch.optim.AdamW keeps it in the group, so its state dict numbers the parameters
+    with it.  FusedAdamW must number them the same way, skip it in step(), and interchange state both ways."""
+    from vit_amd.optim import FusedAdamW
+
+    def build(seed):
+        ps = [torch.nn.Parameter(t.clone().cuda()) for t in make_params(seed)]
+        ps[1].requires_grad_(False)                      # frozen, in the middle of the first group
+        return ps, [{"params": ps[:3], "lr": 1e-3}, {"params": ps[3:], "lr": 2e-3}]
+
+    ref_p, ref_g = build(0)
+    my_p, my_g = build(0)
+    ref = torch.optim.AdamW(ref_g, weight_decay=0.05)
+    mine = FusedAdamW(my_g, weight_decay=0.05)
+    assert [len(g["params"]) for g in mine.param_groups] == [len(g["params"]) for g in ref.param_groups]
+    frozen_before = my_p[1].detach().clone()
+    for step in range(2):
+        grads = make_params(300 + step)
+        for i, (a, b, g) in enumerate(zip(ref_p, my_p, grads)):
+            if i != 1:
+                a.grad, b.grad = g.cuda(), g.cuda()
+        ref.step()
+        mine.step()
+    for a, b in zip(ref_p, my_p):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7)
+    assert torch.equal(my_p[1], frozen_before)
+    sd, sd_ref = mine.state_dict(), ref.state_dict()
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in sd_ref["param_groups"]]
+    assert set(sd["state"].keys()) == set(sd_ref["state"].keys()) and 1 not in sd["state"]
+    # both directions of the interchange, then one more step everywhere
+    p2, g2 = build(0)
+    p3, g3 = build(0)
+    for dst, src in zip(p2 + p3, my_p + my_p):
+        dst.data.copy_(src.data)
+    from_torch = FusedAdamW(g2, weight_decay=0.05)
+    from_torch.load_state_dict(sd_ref)
+    to_torch = torch.optim.AdamW(g3, weight_decay=0.05)
+    to_torch.load_state_dict(sd)
+    grads = make_params(777)
+    for plist in (my_p, p2, p3):
+        for i, (p, g) in enumerate(zip(plist, grads)):
+            if i != 1:
+                p.grad = g.cuda()
+    for o in (mine, from_torch, to_torch):
+        o.step()
+    for a, b, c in zip(my_p, p2, p3):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7) and torch.allclose(a, c, rtol=2e-6, atol=2e-7)
+    # unfreezing after construction is refused with a message instead of writing moments nowhere
+    my_p[1].requires_grad_(True)
+    my_p[1].grad = torch.zeros_like(my_p[1])
+    with pytest.raises(ValueError, match="frozen"):
+        mine.step()

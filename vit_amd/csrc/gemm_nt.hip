@@ -567,6 +567,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     constexpr int RING = 5, LPS = 8;              // loads per thread and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    const uint64_t t_entry = DBG == 5 ? __builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 #define VA_PIN asm volatile("" ::: "memory")
     // One stage: 64 MFMAs; the next stage's fragments are read into the registers just retired and the eight
     // loads of the stage four ahead (stage kt_load of tile `lt`) go out one per row block.
-    u32x4_t sink[2][8];          // DBG 6 / 7 only
+    u32x4_t sink[2][8];          // DBG 6 / 7 only (timing-only instantiations of the diagnostic library)
     auto lds_off_dbg = [&](int sl) { return (uint32_t)(uintptr_t)(lds_ptr_t)(smem + sl * STAGE_BYTES); };
     if (DBG == 6 || DBG == 7) {
 #pragma unroll
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     // next one (read by this stage's prefetch) and the barrier tells that every wave has taken the current stage
     // into registers and is done with the previous one, whose slot the stage four ahead refills during this body.
     int slot = 0;                                          // ring slot of the current stage
-    uint64_t t_sync = 0, t_body = 0, t_epi = 0, t_last = 0;          // DBG 5: cycles in waits+barriers / in stage bodies
+    uint64_t t_sync = 0, t_body = 0, t_epi = 0, t_last = 0, t_first = 0, w_first = 0;   // DBG 5: cycles in waits+barriers / in stage bodies
     // `relaxed`: the first three stages after the epilogue of a tile whose rows all exist.  Memory operations
     // retire in issue order and the loads of this tile's stages 1..3 went out before the epilogue's stores, so the
     // loads a stage needs are followed by two stages' loads AND those stores (32 instructions per wave for one
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     };
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
-    if (DBG == 5) t_last = __builtin_amdgcn_s_memtime();
+    if (DBG == 5) { t_last = t_first = __builtin_amdgcn_s_memtime(); w_first = __builtin_amdgcn_s_memrealtime(); }
     bool after_epilogue = false;
     for (;;) {
         // the tile whose first four stages ride in this tile's last four bodies; after the last tile the same
@@ -807,10 +808,14 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 9; ++i) tk[i] = 0;
     }
-    if (DBG == 5 && lane == 0) {
-        float* o = (float*)ep.out + ((size_t)blockIdx.x * 4 + wave) * 4;
-        const uint64_t now = __builtin_amdgcn_s_memtime();
+    if (DBG == 5 && lane == 0) {     // diagnostic instantiation only: the stamps leave through a buffer of their own
+        float* o = (float*)ep.out2 + ((size_t)blockIdx.x * 4 + wave) * 8;
+        const uint64_t now = __builtin_amdgcn_s_memtime(), wall = __builtin_amdgcn_s_memrealtime();
         o[0] = (float)t_sync; o[1] = (float)t_body; o[2] = (float)(now - t_last); o[3] = (float)t_epi;
+        o[4] = (float)(now - t_first);          // shader cycles from the first stage to here
+        o[5] = (float)(wall - w_first);         // the same span in ticks of the constant 100 MHz clock
+        o[6] = (float)(t_first - t_entry);      // prologue: kernel entry to the first stage (cycles)
+        o[7] = 0.f;
     }
 #endif
 }
@@ -889,9 +894,11 @@ int* quad_ticket_set(int dev, hipStream_t stream, bool* none) {
     return t.base + (t.used++) * 16;
 }
 
+// DBG != 0 and grid_limit are for the diagnostic library built from tools/gemm_nt_debug.hip; this file instantiates
+// DBG = 0 only.
 template <int EPI, bool HAS_BIAS, int DBG = 0>
 int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, int ldw, const EpiArgs& ep,
-                hipStream_t stream) {
+                hipStream_t stream, int grid_limit = 0) {
     constexpr int LDS = 5 * 2 * 256 * 32 * 2;
     auto kern = gemm_nt_quad_kernel<EPI, HAS_BIAS, DBG>;
     static bool flags[64] = {};
@@ -905,9 +912,7 @@ int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
             cus[dev] = 256;
     }
     int grid = tiles < cus[dev & 63] ? tiles : cus[dev & 63];
-#ifdef VA_GEMM_DEBUG_VARIANTS   // fewer workgroups than CUs: does a tile's epilogue or stage get faster with less company?
-    if (const char* g = getenv("VA_QUAD_GRID")) grid = atoi(g) < grid ? atoi(g) : grid;
-#endif
+    if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     bool none = false;
     int* tk = quad_ticket_set(dev, stream, &none);
     if (none) return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
@@ -928,14 +933,6 @@ int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, 
         if (EPI == VA_EPI_BF16 && ep.bias == nullptr) return launch_quad<EPI, EPI != VA_EPI_BF16>(X, W, M, N, K, ldx, ldw, ep, stream);
         return launch_quad<EPI, EPI != VA_EPI_GELU_BWD>(X, W, M, N, K, ldx, ldw, ep, stream);
     }
-#ifdef VA_GEMM_DEBUG_VARIANTS   // timing experiments only (results are wrong): no loads / no fragment reads / no barrier
-    if (EPI == VA_EPI_BF16 && tile == 4257) return launch_quad<VA_EPI_BF16, false, 1>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (EPI == VA_EPI_BF16 && tile == 4258) return launch_quad<VA_EPI_BF16, false, 2>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (EPI == VA_EPI_BF16 && tile == 4259) return launch_quad<VA_EPI_BF16, false, 3>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (EPI == VA_EPI_BF16 && tile == 4261) return launch_quad<VA_EPI_BF16, false, 5>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (EPI == VA_EPI_BF16 && tile == 4263) return launch_quad<VA_EPI_BF16, false, 6>(X, W, M, N, K, ldx, ldw, ep, stream);
-    if (EPI == VA_EPI_BF16 && tile == 4264) return launch_quad<VA_EPI_BF16, false, 7>(X, W, M, N, K, ldx, ldw, ep, stream);
-#endif
     if (tile == 1256) return launch_pair<256, 256, 2, 4, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
     return launch_pair<128, 128, 2, 2, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
 }
@@ -966,7 +963,7 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
         const bool quad = epilogue == VA_EPI_BF16 || (epilogue == VA_EPI_F32 && drop_thresh16 == 0);
         tile = !big ? 128 : quad ? 4256 : 256;
     }
-    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || (tile >= 4256 && tile <= 4264)) && N % 256 == 0 && K >= 128),
+    VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || tile == 4256) && N % 256 == 0 && K >= 128),
                  "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
     VA_CHECK_ARG(drop_thresh16 == 0 || tile < 4256, "va_gemm_nt_dropout: the four-wave kernel (tile %d) has no dropout epilogue", tile);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc, drop_key, drop_thresh16 << 16,

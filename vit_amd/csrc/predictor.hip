@@ -87,16 +87,34 @@ __global__ __launch_bounds__(2 * HD) __attribute__((amdgpu_waves_per_eu(2))) voi
 
     // Staging of a chunk: direct-to-LDS loads issued at the start of the previous chunk and waited for at its end.
     // They are written as assembly because the compiler, not knowing which LDS bytes such a load writes, would
-    // otherwise drain the vector-memory counter before every LDS read of the step loop.  (m0 holds nothing of the
-    // compiler's between statements in this kernel: it sets it only for instructions of this kind.  The s_nop is the
-    // wait state between a scalar write of m0 and an instruction that reads it.)
+    // otherwise drain the vector-memory counter before every LDS read of the step loop.  m0 (the LDS destination
+    // base of such a load) is the compiler's register and cannot be named as a clobber, so the statement saves it,
+    // sets it, and restores it itself; the s_nop is the wait state between a scalar write of m0 and an instruction
+    // that reads it.
     const int r_in_pass = i * 4 / HD, col = (i * 4) % HD;     // this lane's 16 bytes inside a pass
     const int wave = __builtin_amdgcn_readfirstlane(i >> 6);
     auto to_lds = [](const float* src, const float* lds_wave_base) {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                     :: "v"(src), "s"((uint32_t)(uintptr_t)lds_wave_base) : "memory");
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"((uint32_t)(uintptr_t)lds_wave_base) : "memory");
     };
+    // The decay / write-strength pair of a chunk travels through a register instead: an ordinary load, which the
+    // compiler counts.  Its wait would drain the direct-to-LDS loads above if it came after them, so the value for
+    // chunk c + 1 is requested one chunk early (at the start of chunk c - 1, ahead of that chunk's staging loads) and
+    // written to LDS at the start of chunk c, when the wait at the top of the chunk has already emptied the queue.
+    auto ab_load = [&](int chunk) -> float {
+        float x = 0.f;
+        if (i < 2 * GD_T) {
+            int t = chunk * GD_T + i % GD_T;
+            t = t < L ? t : L - 1;
+            x = ab_src[i / GD_T][(int64_t)t * H];
+        }
+        return x;
+    };
+    float ab_next = ab_load(0);
     auto stage = [&](int chunk, int buf) {
+        if (i < 2 * GD_T) ab[buf][i / GD_T][i % GD_T] = ab_next;
+        ab_next = ab_load(chunk + 1);
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             int t = chunk * GD_T + p * ROWS_PER_PASS + r_in_pass;
@@ -106,12 +124,6 @@ __global__ __launch_bounds__(2 * HD) __attribute__((amdgpu_waves_per_eu(2))) voi
             to_lds(kb + off, &ks[buf][0][0] + dst);
             to_lds(qb + off, &qs[buf][0][0] + dst);
             to_lds(vb + off, &vs[buf][0][0] + dst);
-        }
-        if (i < 2 * GD_T) {
-            const int which = i / GD_T, tt = i % GD_T;
-            int t = chunk * GD_T + tt;
-            t = t < L ? t : L - 1;
-            ab[buf][which][tt] = ab_src[which][(int64_t)t * H];
         }
     };
 

@@ -46,9 +46,21 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group: Optional[
                 host = t.data.cpu()
                 dist.broadcast(host, src=src, group=group)
                 t.data.copy_(host)
-    cache = getattr(getattr(module, "_engine_obj", None), "weights", None)
-    if cache is not None:          # writes through .data do not bump version counters: drop cached operand copies
-        cache.invalidate()
+    invalidate_operand_caches(module)
+
+
+def invalidate_operand_caches(module: torch.nn.Module) -> None:
+    """Drop every cached bf16 operand copy of weights below `module` (the encoder engine's, and those of predictor
+    blocks and stand-alone modules).  Needed after parameters were written through `.data` (a broadcast, a raw copy):
+    such writes do not bump the version counters the caches key on, so a forward that ran before the write would
+    otherwise leave stale copies in use."""
+    for sub in module.modules():
+        cache = getattr(getattr(sub, "_engine_obj", None), "weights", None)
+        if cache is not None:
+            cache.invalidate()
+        per_module = sub.__dict__.get("_operand_cache")
+        if per_module is not None:
+            per_module.invalidate()
 
 
 class BucketReducer:
@@ -68,6 +80,11 @@ class BucketReducer:
         self._pending: List[Tuple[object, torch.Tensor, object]] = []
         self.buckets_reduced = 0
         self.bytes_reduced = 0
+        # measure_exposed: bracket every join with device events on the compute stream.  The first event completes
+        # when the last kernel enqueued before the join (the end of backward) is done, the second when the last
+        # bucket's reduction is: the span is the communication time that backward did NOT hide.
+        self.measure_exposed = False
+        self._exposed: List[Tuple[object, object]] = []
 
     def _say(self, msg: str) -> None:
         if self.log is not None:
@@ -103,6 +120,25 @@ class BucketReducer:
 
     def finish(self) -> None:
         """Make the current stream wait for every outstanding bucket (and finish the averaging)."""
+        timed = self.measure_exposed and self._pending and self._pending[0][1].is_cuda
+        if timed:
+            before = torch.cuda.Event(enable_timing=True)
+            before.record()
+        self._finish_pending()
+        if timed:
+            after = torch.cuda.Event(enable_timing=True)
+            after.record()
+            self._exposed.append((before, after))
+
+    def exposed_ms(self) -> List[float]:
+        """Per join since the last call: milliseconds the compute stream spent waiting for reductions after its own
+        work was done (needs `measure_exposed = True`; synchronises the device)."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed.clear()
+        return out
+
+    def _finish_pending(self) -> None:
         for n, (work, flat, tag) in enumerate(self._pending):
             if work is not None:
                 work.wait()
@@ -123,15 +159,23 @@ class BucketReducer:
         norm is only the same on every rank once every gradient has been averaged."""
         if self.world == 1 and not self.always_reduce:
             return
-        with_grad = [p for p in params if p.grad is not None]
-        if with_grad:
-            flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in with_grad])
+        # the bucket covers the FIXED list of trainable parameters, zeros standing in for a missing gradient: its size
+        # and the fact that a collective is issued must not depend on which parameters got a gradient on this rank (an
+        # empty shard, a head one rank did not use), or ranks would disagree about the collective and hang
+        params = [p for p in params if p.requires_grad]
+        if params:
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32)
+                              for p in params])
             self.submit(flat)
             self.finish()
             off = 0
-            for p in with_grad:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            for p in params:
+                n = p.numel()
+                piece = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = piece.to(p.dtype).clone()
+                else:
+                    p.grad.copy_(piece)
                 off += n
         else:
             self.finish()

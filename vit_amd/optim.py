@@ -9,8 +9,10 @@ rewritten).
 `FusedAdamW` is a `torch.optim.Optimizer`: `param_groups` is the persistent list schedulers write `lr` into
 (CosineAnnealingLR s1:391, LambdaLR ft:235-239), and `state_dict()` / `load_state_dict()` use torch.optim.AdamW's
 layout (per parameter `step`, `exp_avg`, `exp_avg_sq`), so the `optimizer` entry of a checkpoint (s1:504) written by
-either optimizer loads into the other.  The moments live in two flat f32 buffers; the per-parameter state tensors
-are views into them.
+either optimizer loads into the other.  Parameters with `requires_grad=False` stay in their groups, as they do in
+torch.optim.AdamW (the frozen encoder of stage1_vjepa2_finetuning.py:166-170 when a caller passes all parameters), so
+the parameter indices and per-group counts of the two state dicts agree; they get no moments and no state entry, and
+are skipped by `step()`.  The moments live in two flat f32 buffers; the per-parameter state tensors are views into them.
 """
 from __future__ import annotations
 
@@ -32,27 +34,29 @@ class FusedAdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("FusedAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
-        for g in self.param_groups:                       # frozen parameters never get a gradient: drop them
-            g["params"] = [p for p in g["params"] if p.requires_grad]
+        # every parameter of every group, frozen ones included: position = its index in the state dict
         self.params: List[torch.nn.Parameter] = [p for g in self.param_groups for p in g["params"]]
-        if not self.params:
+        trainable = [p for p in self.params if p.requires_grad]
+        if not trainable:
             raise ValueError("FusedAdamW: no trainable parameters")
-        dev = self.params[0].device
-        for p in self.params:
+        dev = trainable[0].device
+        for p in trainable:
             if p.dtype != torch.float32 or p.device != dev or not p.is_cuda or not p.is_contiguous():
                 raise ValueError("FusedAdamW needs contiguous f32 parameters on one HIP device")
         self.max_grad_norm = max_grad_norm
         self.device = dev
         offs, total = [], 0
-        for p in self.params:
-            offs.append(total)
-            total += (p.numel() + 3) // 4 * 4            # keep every slice 16-byte aligned
+        for p in self.params:                            # frozen parameters get no slice of the moment buffers
+            offs.append(total if p.requires_grad else None)
+            if p.requires_grad:
+                total += (p.numel() + 3) // 4 * 4        # keep every slice 16-byte aligned
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self._offs = offs
         self._slot = {id(p): i for i, p in enumerate(self.params)}
         for i, p in enumerate(self.params):
-            self.state[p] = self._fresh_state(i, p, 0.0)
+            if offs[i] is not None:
+                self.state[p] = self._fresh_state(i, p, 0.0)
         self.total_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._table_key = None
         self._table = self._partial = self._desc = None
@@ -70,7 +74,7 @@ class FusedAdamW(torch.optim.Optimizer):
         parameter that has not been stepped yet (the predictor under the stage-1 objective, ft:196-232) has no entry:
         the same here, although its slice of the flat buffers exists from the start."""
         sd = super().state_dict()
-        never = {i for i, p in enumerate(self.params) if float(self.state[p]["step"]) == 0.0}
+        never = {i for i, p in enumerate(self.params) if p in self.state and float(self.state[p]["step"]) == 0.0}
         sd["state"] = {k: v for k, v in sd["state"].items() if k not in never}
         return sd
 
@@ -81,6 +85,10 @@ class FusedAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         for i, p in enumerate(self.params):
             st = self.state.get(p)
+            if self._offs[i] is None:                    # frozen here: nothing to keep for it
+                if st:
+                    del self.state[p]
+                continue
             if not st:                                   # a parameter the saved optimizer had not stepped yet
                 o, n = self._offs[i], p.numel()
                 self.exp_avg[o:o + n].zero_()
@@ -137,6 +145,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 gr = p.grad
                 if gr.dtype != torch.float32 or not gr.is_contiguous() or gr.device != self.device:
                     raise ValueError("FusedAdamW: gradients must be contiguous f32 on the parameters' device")
+                if self._offs[self._slot[id(p)]] is None:
+                    raise ValueError("FusedAdamW: a parameter that was frozen (requires_grad=False) when the optimizer "
+                                     "was built has a gradient now; build the optimizer after unfreezing it")
                 grp.append((self._slot[id(p)], p))
             live_by_group.append(grp)
         if not any(live_by_group):

@@ -402,6 +402,25 @@ def _hip_inference(x: torch.Tensor, module: Optional[nn.Module] = None) -> bool:
     return module is None or not any(p.requires_grad for p in module.parameters())
 
 
+_warned_torch_path = False
+
+
+def _note_torch_path(x: torch.Tensor, who: str) -> None:
+    """Tell the caller, once per process, that a predictor call on the device is being computed by the torch
+    formulation instead of the HIP kernels because an autograd graph is wanted (grad mode on and trainable parameters,
+    or an input that requires grad).  A model called without `torch.no_grad()` would otherwise take the slow path
+    silently."""
+    global _warned_torch_path
+    if _warned_torch_path or not (x.is_cuda and x.dtype == torch.float32):
+        return
+    _warned_torch_path = True
+    import warnings
+    warnings.warn(f"{who}: grad mode is on and the predictor has trainable parameters (or its input requires grad), so "
+                  "this call is computed by the torch formulation (a per-token Python loop for the memory layer), not "
+                  "by the HIP kernels. For inference wrap the call in torch.no_grad(); the kernels have no predictor "
+                  "backward.", RuntimeWarning, stacklevel=3)
+
+
 class GatedDeltaLayer(nn.Module):
     """Gated delta-rule memory layer (swm:431-555).  Only the sequential recurrence is provided: it is the
     form inference uses and the one the reference's other ("parallel") path fails to reproduce."""
@@ -456,6 +475,8 @@ class GatedDeltaLayer(nn.Module):
                                                  v.contiguous().view(B, L, H, Dh), alpha.contiguous(), beta.contiguous(),
                                                  None if state is None else state.contiguous())
         else:
+            if Dh in (64, 128):
+                _note_torch_path(x, "GatedDeltaLayer.forward")
             q = F.normalize(self.silu(self._causal_conv(self.q_conv1d, self.q_proj(x))), p=2, dim=-1)
             k = F.normalize(self.silu(self._causal_conv(self.k_conv1d, self.k_proj(x))), p=2, dim=-1)
             v = self.silu(self._causal_conv(self.v_conv1d, self.v_proj(x)))
@@ -545,6 +566,8 @@ class HybridPredictorBlock(nn.Module):
             if getattr(self, "_operand_cache", None) is None:
                 self._operand_cache = WeightCache()
             return predictor_engine.block_forward(self, x, tpt, state, self._operand_cache)
+        if not _hip_inference(x, self):
+            _note_torch_path(x, "HybridPredictorBlock.forward")
         x = x + self._masked_attention(self.norm1(x), attn_mask)
         if self.use_deltanet:
             delta, state = self.temporal_layer(x, state)
