@@ -154,7 +154,9 @@ def test_frozen_parameters_keep_their_place_in_the_state_dict():
     for a, b in zip(ref_p, my_p):
         assert torch.allclose(a, b, rtol=2e-6, atol=2e-7)
     assert torch.equal(my_p[1], frozen_before)
-    sd, sd_ref = mine.state_dict(), ref.state_dict()
+    import copy
+    # deep copies, as a checkpoint file would hold: a state dict's tensors are references to the live moments
+    sd, sd_ref = copy.deepcopy(mine.state_dict()), copy.deepcopy(ref.state_dict())
     assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in sd_ref["param_groups"]]
     assert set(sd["state"].keys()) == set(sd_ref["state"].keys()) and 1 not in sd["state"]
     # both directions of the interchange, then one more step everywhere
