@@ -745,6 +745,352 @@ __global__ __launch_bounds__(256, HD <= 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dK/dV pass, head dim 64, whole tiles, no mask code: the same arithmetic as attn_bwd_dkv_kernel, software-pipelined.
+//
+// In the kernel above a wave issues a block's score MFMAs, waits for them, runs the block's exponentials with the
+// matrix pipe idle, then issues the gradient MFMAs; a second wave on the SIMD covers little of that (each wave issues in
+// order, and both want the same pipe at the same time).  Here ONE wave per SIMD owns 64 keys (two 32-key sub-blocks, so
+// every query fragment read from LDS feeds twice the MFMAs) and walks (32-query, 32-key) blocks in steps that never
+// leave the matrix pipe waiting for their own vector work: while the 10 MFMAs of the NEXT block's S and dP issue, the
+// exp2 / multiply / convert instructions of the CURRENT block sit in the gaps between them, and so do the 8 MFMAs that
+// add the PREVIOUS block into dV and dK and the LDS reads of later blocks.  S/dP, the packed operands and both kinds of
+// streamed fragments are double-buffered in registers (the sub-block / query-block index is the parity), so nothing a
+// step's MFMAs consume is produced inside that step and nothing is copied.
+//
+// A wave issues in order, so the schedule IS the instruction order.  Every MFMA and every vector instruction of the loop
+// is a volatile asm statement (volatile statements keep their order), LDS reads are ordinary loads fenced by empty
+// memory-clobbering statements (which pins them between the same MFMAs), and the order itself comes from
+// tools/gen_attn_dkv.py (attn_dkv64_body.inc) together with the distances it keeps: the hardware does not interlock a
+// vector read of an MFMA result, nor the use of a v_exp_f32 result by the next instruction.
+// Accumulators (dK, dV: a[0:127], named literally), the stationary key / value fragments and the streamed row fragments
+// of Q / dO (LDS reads land there directly) fill the accumulation half of the register file; scores, probabilities,
+// packed operands and the transposed fragments live in the other half.
+// Results are bit-identical to attn_bwd_dkv_kernel: every accumulation chain sees the same terms in the same order.
+// ------------------------------------------------------------------------------------------------
+#define DKV_PIN0 asm volatile("" ::: "memory")
+#ifndef VA_DKV64_BODY            // a diagnostic build may name another (timing-only) instruction order
+#define VA_DKV64_BODY "attn_dkv64_body.inc"
+#endif
+constexpr int DKV64_SLOTS = 4;
+constexpr int DKV64_STAGE = 2 * TILE_ROWS * 64 * 2 + TILE_ROWS * 16;     // Q | dO | records of one 64-query tile
+
+// dK and dV (8 accumulators of 16 registers) live in a[0:127], named literally in the instruction text.  They are not
+// C++ values: left to the register allocator, a loop-carried accumulator that only asm statements touch is parked in
+// vector registers between its uses and copied in and out around every MFMA.  EVERY MFMA statement of the kernel lists
+// a0..a127 as clobbered, so the compiler never places a value that lives across one of them (the streamed fragments
+// always do) into that block, and the kernel descriptor reserves it.
+#define VA_ACC128 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+VA_DEVINL void mfz_vv(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) {      // D = A * B (all in vector registers)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b) : VA_ACC128);
+}
+VA_DEVINL void mf_aa(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) {       // D += A * B, A and B in accumulation registers
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b) : VA_ACC128);
+}
+template <int R>                                                                // accumulator R (a[16R : 16R+15]) += A * B
+VA_DEVINL void mf_acc(const bf16x8_t& a, const bf16x8_t& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(16 * R), "n"(16 * R + 15) : VA_ACC128);
+}
+template <int R>                                                                // accumulator R = 0 (0 * 0 + 0)
+VA_DEVINL void mf_acc_clear(const bf16x8_t& zero) {
+    // s_nop: the compiler materialises `zero` with a move right in front of this statement and pads no wait states
+    // between a vector write and an MFMA it cannot see inside an asm statement
+    asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" ::"v"(zero), "n"(16 * R), "n"(16 * R + 15) : VA_ACC128);
+}
+template <int I>
+VA_DEVINL float acc_read() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "n"(I));
+    return x;
+}
+template <int R>
+VA_DEVINL f32x16_t acc_tile() {
+    return (f32x16_t){acc_read<16 * R + 0>(), acc_read<16 * R + 1>(), acc_read<16 * R + 2>(), acc_read<16 * R + 3>(),
+                      acc_read<16 * R + 4>(), acc_read<16 * R + 5>(), acc_read<16 * R + 6>(), acc_read<16 * R + 7>(),
+                      acc_read<16 * R + 8>(), acc_read<16 * R + 9>(), acc_read<16 * R + 10>(), acc_read<16 * R + 11>(),
+                      acc_read<16 * R + 12>(), acc_read<16 * R + 13>(), acc_read<16 * R + 14>(), acc_read<16 * R + 15>()};
+}
+VA_DEVINL float a_exp2(float x) { float r; asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+VA_DEVINL float a_mul(float x, float y) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+VA_DEVINL uint32_t a_cvt_pk(float lo, float hi) {
+    uint32_t r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// STAMPS (diagnostic library only, tools/attn_debug.hip): s_memtime stamps around the parts of a tile, summed per wave and
+// written to `stamps` (8 floats per wave: tile-top waits + barrier + staging, the four steps, prologue, epilogue, tiles).
+template <bool STAMPS = false>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ V, const bf16_t* __restrict__ DO,
+                                                                const u32x4_t* __restrict__ AUX, bf16_t* __restrict__ DK,
+                                                                bf16_t* __restrict__ DV, int N, int H, int64_t ld, int64_t ldo,
+                                                                int64_t lddq, float c, float scale, float* __restrict__ stamps) {
+    uint64_t tm[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+    auto stamp = [&](int i) {
+        if constexpr (STAMPS) {
+            __builtin_amdgcn_sched_barrier(0);
+            uint64_t now;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            tm[i] += now - t_last;
+            t_last = now;
+        }
+    };
+    if constexpr (STAMPS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+    constexpr int HD = 64, KS = 4, TB = TILE_ROWS * HD * 2, STAGE = DKV64_STAGE, NSL = DKV64_SLOTS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NSL][STAGE] | 16 zero bytes
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Every workgroup does the same work, so the CUs would run their prologue loads (K, V and three tiles: 115 KiB) and
+    // their epilogue stores (64 KiB) all at the same moments, launch after launch of workgroups, at a fraction of the
+    // rate a lone CU gets.  The workgroups of the first round -- one per CU -- therefore start up to ~10k cycles apart;
+    // the CUs keep that phase for the rest of the launch.
+    {
+        const unsigned first_round = blockIdx.y * gridDim.x + blockIdx.x;
+        if (first_round < 256u) {
+            const int naps = (int)((first_round * 37u) & 63u);
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(2);          // ~160 cycles each
+        }
+    }
+    const HeadBlock hb = head_block();
+    const int bh = hb.bh, b = bh / H, hh = bh % H;
+    const int k0 = hb.blk * 256 + wave * 64;
+    const bf16_t* Qb = Q + (int64_t)b * N * ld + hh * HD;
+    const bf16_t* Kb = K + (int64_t)b * N * ld + hh * HD;
+    const bf16_t* Vb = V + (int64_t)b * N * ld + hh * HD;
+    const bf16_t* DOb = DO + (int64_t)b * N * ldo + hh * HD;
+    const u32x4_t* aux_b = AUX + (int64_t)bh * N;
+
+    // stationary operands as loaded (the key fragments carry the softmax scale); they move to accumulation registers
+    // further down, once the first tiles are on their way
+    bf16x8_t kf0[2][KS], vf0[2][KS];
+    bf16x8_t kf[2][KS], vf[2][KS];               // ... and where the MFMAs take them from
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int krow = k0 + kb * 32 + (lane & 31);
+        const int krow_c = krow < N ? krow : N - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf0[kb][ks] = *(const bf16x8_t*)(Kb + (int64_t)krow_c * ld + ks * 16 + h * 8);
+            vf0[kb][ks] = *(const bf16x8_t*)(Vb + (int64_t)krow_c * ld + ks * 16 + h * 8);
+        }
+    }
+    // A query's record {-lse2 as three bf16 terms + 0 | -delta likewise} is the A operand of the first MFMA of BOTH
+    // chains as it stands: the B operand selects the half that counts, 1.0 at k = 0..2 for the scores and at k = 4..6
+    // for dP (lane half 0 holds k = 0..7), zero everywhere else.
+    const u32x4_t ones_lse_u = {h == 0 ? 0x3f803f80u : 0u, h == 0 ? 0x00003f80u : 0u, 0u, 0u};
+    const u32x4_t ones_dl_u = {0u, 0u, h == 0 ? 0x3f803f80u : 0u, h == 0 ? 0x00003f80u : 0u};
+    const bf16x8_t ones_lse = __builtin_bit_cast(bf16x8_t, ones_lse_u), ones_dl = __builtin_bit_cast(bf16x8_t, ones_dl_u);
+    char* const zero16 = smem + NSL * STAGE;
+    if (tid < 4) ((uint32_t*)zero16)[tid] = 0u;       // what lane half 1 reads as its (all-zero) record
+
+    {   // accumulator R = 4 * (key sub-block) + 2 * (0: dV, 1: dK) + (32-column half of the head dim)
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, z);
+        mf_acc_clear<0>(zero); mf_acc_clear<1>(zero); mf_acc_clear<2>(zero); mf_acc_clear<3>(zero);
+        mf_acc_clear<4>(zero); mf_acc_clear<5>(zero); mf_acc_clear<6>(zero); mf_acc_clear<7>(zero);
+    }
+
+    const int nt = N / TILE_ROWS;
+    TileSrc<HD> ts_q, ts_do;
+    ts_q.init(ld, tid);
+    ts_do.init(ldo, tid);
+    auto stage = [&](int tile, int slot) {
+        char* nb = smem + slot * STAGE;
+        stage_tile_at<HD, false>(ts_q, Qb, ld, tile * TILE_ROWS, N, nb, tid, wave);
+        stage_tile_at<HD, false>(ts_do, DOb, ldo, tile * TILE_ROWS, N, nb + TB, tid, wave);
+        glds16(aux_b + tile * TILE_ROWS + lane, nb + 2 * TB);      // 64 records of 16 bytes (every wave: the same 1 KiB)
+    };
+
+    f32x16_t s[2], dp[2];                    // two sets, by key sub-block: one is consumed while the other is produced
+    // streamed fragments, two sets each by query-block parity: one is read from LDS while the other feeds MFMAs
+    bf16x8_t qfr[2][KS], dofr[2][KS], recf[2];        // row fragments of a query block (+ its records)
+    bf16x8_t dotr[2][2][2], qtr[2][2][2];             // transposed fragments of a query block
+    bf16x8_t pfr[2][2], dsfr[2][2];                   // packed P and dS, two sets by key sub-block: made in one step, consumed in the next
+    // what the in-step loads of a tile need (set at the top of the tile): source row, destination slot
+    int64_t ld_row0 = 0;
+    char* ld_dst = smem;
+
+#define DKV_PIN asm volatile("" ::: "memory")
+#define MF_S0() mfz_vv(s[KBN], recf[QBN], ones_lse)
+#define MF_S(ks) mf_aa(s[KBN], qfr[QBN][ks], kf[KBN][ks])
+#define MF_P0() mfz_vv(dp[KBN], recf[QBN], ones_dl)
+#define MF_P(ks) mf_aa(dp[KBN], dofr[QBN][ks], vf[KBN][ks])
+#define MF_DV(sx, cb) mf_acc<4 * KBP + (cb)>(dotr[QBP][sx][cb], pfr[KBP][sx])
+#define MF_DK(sx, cb) mf_acc<4 * KBP + 2 + (cb)>(qtr[QBP][sx][cb], dsfr[KBP][sx])
+#define EXP(i) p[i] = a_exp2(s[KB][i])
+#define MUL(i) d[i] = a_mul(p[i], dp[KB][i])
+#define CVP(sx, q) pw[sx][q] = a_cvt_pk(p[8 * (sx) + 2 * (q)], p[8 * (sx) + 2 * (q) + 1])
+#define CVD(sx, q) dw[sx][q] = a_cvt_pk(d[8 * (sx) + 2 * (q)], d[8 * (sx) + 2 * (q) + 1])
+#define PACKP(sx) pfr[KB][sx] = __builtin_bit_cast(bf16x8_t, (u32x4_t){pw[sx][0], pw[sx][1], pw[sx][2], pw[sx][3]})
+#define PACKD(sx) dsfr[KB][sx] = __builtin_bit_cast(bf16x8_t, (u32x4_t){dw[sx][0], dw[sx][1], dw[sx][2], dw[sx][3]})
+    // reads of the NEXT query block NQ = QB ^ 1 (of this tile for QB = 0, the next tile's first one for QB = 1) into
+    // fragment set NQ: its row fragments in the first key sub-block's step, its transposed fragments in the second's
+#define RD_DOT(sx, cb) DKV_PIN; dotr[NQ][sx][cb] = tr_frag<HD>(nsrc + TB, NQ * 32 + 16 * (sx), cb, lane); DKV_PIN
+#define RD_QT(sx, cb) DKV_PIN; qtr[NQ][sx][cb] = tr_frag<HD>(nsrc, NQ * 32 + 16 * (sx), cb, lane); DKV_PIN
+#define RD_REC() DKV_PIN; recf[NQ] = __builtin_bit_cast(bf16x8_t, *(const u32x4_t*)(h == 0 ? nsrc + 2 * TB + (NQ * 32 + (lane & 31)) * 16 : zero16)); DKV_PIN
+#define RD_Q(ks) DKV_PIN; qfr[NQ][ks] = row_frag<HD>(nsrc, NQ * 32, ks, lane); DKV_PIN
+#define RD_DO(ks) DKV_PIN; dofr[NQ][ks] = row_frag<HD>(nsrc + TB, NQ * 32, ks, lane); DKV_PIN
+    // the global -> LDS loads of the tile three ahead: 2 x Q chunks, 2 x dO chunks, the 64 records; one per step of a tile
+    // (LD_STEP), the records with the last.  TILE_SYNC, inside the last step of tile t: this wave's loads of tile t + 2
+    // have landed (those of tile t + 3, issued during this tile, may still be in flight), then the barrier: they have
+    // landed everywhere, and nobody reads tile t any more (its slot is refilled from the next step on).
+#define LD_TILE(i)                                                                                                       \
+    DKV_PIN;                                                                                                             \
+    if constexpr ((i) < 2) glds16((const char*)(Qb + ld_row0 * ld) + ts_q.off[(i) & 1], ld_dst + (((i) & 1) * 256 + wave * 64) * 16);         \
+    else if constexpr ((i) < 4) glds16((const char*)(DOb + ld_row0 * ldo) + ts_do.off[(i) & 1], ld_dst + TB + (((i) & 1) * 256 + wave * 64) * 16); \
+    else glds16(aux_b + ld_row0 + lane, ld_dst + 2 * TB);     /* every wave: same 1 KiB, no branch in the step */        \
+    DKV_PIN
+#define LD_STEP()                                   \
+    LD_TILE(2 * QB + KB);                           \
+    if constexpr (2 * QB + KB == 3) { LD_TILE(4); }
+#define TILE_SYNC()                                 \
+    wait_vm<5>();                                   \
+    asm volatile("" ::: "memory");                  \
+    __builtin_amdgcn_s_barrier();                   \
+    asm volatile("" ::: "memory")
+
+    // One step: block (QB, KB) of the tile at LDS address `cur` is the current one; `nxt_tile` is the tile after it.
+    // The S / dP of the next block are always produced and the later fragments always read -- also at the very end, where
+    // they come from a slot that holds an older tile and are never used: the loop body stays one straight line of code
+    // without branches.
+    auto step = [&](auto qb_c, auto kb_c, const char* cur, const char* nxt_tile) {
+        constexpr int QB = decltype(qb_c)::value, KB = decltype(kb_c)::value;
+        constexpr int KBN = KB ^ 1;                                          // the next block: key sub-block ...
+        constexpr int QBN = KB == 0 ? QB : QB ^ 1;                           // ... and query block (= its fragment set)
+        constexpr int KBP = KB ^ 1, QBP = KB == 0 ? QB ^ 1 : QB;             // the previous block (its dV / dK MFMAs run now)
+        constexpr int NQ = QB ^ 1;                                           // the query block whose fragments are read
+        const char* nsrc = QB == 0 ? cur : nxt_tile;                         // ... and the tile it lies in
+        float p[16], d[16];
+        uint32_t pw[2][4], dw[2][4];
+        (void)nsrc;
+#include VA_DKV64_BODY
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    stage(0, 0);
+    stage(nt > 1 ? 1 : 0, 1);
+    stage(nt > 2 ? 2 : nt - 1, 2);
+    // The stationary fragments belong in accumulation registers (the vector half is needed for scores and packed
+    // operands), and a value only gets there without a copy in front of every use when the instruction that DEFINES it
+    // writes there: an LDS read can, a conversion cannot.  So they take one round trip through this wave's 4 KiB of the
+    // fourth ring slot (free until the first step's load), four fragments at a time, while the tiles are in flight.
+    {
+        char* scr = smem + 3 * STAGE + wave * 4096 + lane * 16;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) *(bf16x8_t*)(scr + ks * 1024) = scale_frag(kf0[kb][ks], c);
+            DKV_PIN0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const bf16x8_t*)(scr + ks * 1024);
+            DKV_PIN0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) *(bf16x8_t*)(scr + ks * 1024) = vf0[kb][ks];
+            DKV_PIN0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) vf[kb][ks] = *(const bf16x8_t*)(scr + ks * 1024);
+            DKV_PIN0;
+        }
+    }
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {   // prologue: what the first step expects in place -- row and transposed fragments of query block 0 of tile 0
+        // (set 0) -- and S / dP of block (0, 0) into set 0
+        const char* nsrc = smem;
+        constexpr int NQ = 0;
+        RD_REC(); RD_Q(0); RD_Q(1); RD_Q(2); RD_Q(3); RD_DO(0); RD_DO(1); RD_DO(2); RD_DO(3);
+        RD_DOT(0, 0); RD_DOT(0, 1); RD_QT(0, 0); RD_QT(0, 1); RD_DOT(1, 0); RD_DOT(1, 1); RD_QT(1, 0); RD_QT(1, 1);
+        constexpr int QBN = 0, KBN = 0;
+        MF_S0(); MF_S(0); MF_S(1); MF_S(2); MF_S(3);
+        MF_P0(); MF_P(0); MF_P(1); MF_P(2); MF_P(3);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the first vector reads of these results follow closely
+        // the first step adds a "previous block" that does not exist: all-zero operands (set 1 of both) make it add zero
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, z);
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            pfr[1][sx] = zero; dsfr[1][sx] = zero;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) { dotr[1][sx][cb] = zero; qtr[1][sx][cb] = zero; }
+        }
+    }
+    stamp(5);
+    int slot = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int slot1 = (slot + 1) & (NSL - 1), slot3 = (slot + 3) & (NSL - 1);
+        // the steps of this tile load tile t + 3 into the slot tile t - 1 has left; past the end the last tile once more
+        // (never read)
+        ld_row0 = (int64_t)(t + 3 < nt ? t + 3 : nt - 1) * TILE_ROWS;
+        ld_dst = smem + slot3 * STAGE;
+        const char* cur = smem + slot * STAGE;
+        const char* nxt_tile = smem + slot1 * STAGE;
+        stamp(0);
+        step(I0{}, I0{}, cur, nxt_tile);
+        stamp(1);
+        step(I0{}, I1{}, cur, nxt_tile);
+        stamp(2);
+        step(I1{}, I0{}, cur, nxt_tile);
+        stamp(3);
+        step(I1{}, I1{}, cur, nxt_tile);
+        stamp(4);
+        slot = slot1;
+    }
+    {   // the last block's dV / dK (its packed operands were made in the last step)
+        constexpr int KBP = 1, QBP = 1;
+        MF_DV(0, 0); MF_DV(0, 1); MF_DK(0, 0); MF_DK(0, 1); MF_DV(1, 0); MF_DV(1, 1); MF_DK(1, 0); MF_DK(1, 1);
+    }
+    wait_vm0();        // the trailing loads must not land in LDS after the workgroup has gone
+#undef DKV_PIN
+#undef MF_S0
+#undef MF_S
+#undef MF_P0
+#undef MF_P
+#undef MF_DV
+#undef MF_DK
+#undef EXP
+#undef MUL
+#undef CVP
+#undef CVD
+#undef PACKP
+#undef PACKD
+#undef RD_DOT
+#undef RD_QT
+#undef RD_REC
+#undef RD_Q
+#undef RD_DO
+#undef LD_TILE
+#undef LD_STEP
+#undef TILE_SYNC
+    // the asm MFMAs are opaque to the compiler's hazard tracking: let the last results retire before they are read
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    auto store_sub = [&](auto kb_c) {
+        constexpr int kb = decltype(kb_c)::value;
+        const f32x16_t dvt[2] = {acc_tile<4 * kb + 0>(), acc_tile<4 * kb + 1>()};
+        const f32x16_t dkt[2] = {acc_tile<4 * kb + 2>(), acc_tile<4 * kb + 3>()};
+        const int krow = k0 + kb * 32 + (lane & 31);
+        if (krow < N) {
+            store_rows<HD>(dkt, scale, DK + ((int64_t)b * N + krow) * lddq + hh * HD, h);
+            store_rows<HD>(dvt, 1.0f, DV + ((int64_t)b * N + krow) * lddq + hh * HD, h);
+        }
+    };
+    store_sub(std::integral_constant<int, 0>{});
+    store_sub(std::integral_constant<int, 1>{});
+    if constexpr (STAMPS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(6);
+        if (lane == 0) {
+            float* o = stamps + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) o[i] = (float)tm[i];
+            o[7] = (float)nt;
+        }
+    }
+}
+
 template <typename KernT>
 int set_lds(KernT kern, int bytes, bool* flags, const char* who) {
     int dev = 0;
@@ -795,6 +1141,12 @@ int fwd_launch(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, flo
     return fwd_launch_mode<HD, 0, false>(q, k, v, o, lse2, B, N, H, ld, ldo, 0, drop, stream);
 }
 
+// VA_ATTN_DKV_GENERIC=1 in the environment keeps every shape on the generic dK/dV kernel (A/B timing, cross-checks).
+inline bool dkv_generic_only() {
+    static const bool v = [] { const char* e = getenv("VA_ATTN_DKV_GENERIC"); return e && e[0] == '1'; }();
+    return v;
+}
+
 template <int HD, bool RAGGED, bool DROP, bool BITS = false>
 int bwd_launch_as(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* o, const bf16_t* d_o,
                   const float* lse2, float* workspace, bf16_t* dq, bf16_t* dk, bf16_t* dv, int B, int N, int H,
@@ -817,6 +1169,16 @@ int bwd_launch_as(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, RAGGED, DROP, BITS>), grid, dim3(256), LDS_DQ, stream, q, k, v, o, d_o, lse2,
                        delta, aux, dq, N, H, ld, ldo, lddq, c, scale, DROP ? 1.0f / drop.scale : 1.0f, drop, mask);
     VA_CHECK_LAUNCH("va_attn_bwd(dq)");
+    if (HD == 64 && !RAGGED && !DROP && !BITS && !dkv_generic_only()) {
+        constexpr int LDS_P = DKV64_SLOTS * DKV64_STAGE + 16;
+        static bool f3[64] = {};
+        if (int e = set_lds(attn_bwd_dkv64_kernel<false>, LDS_P, f3, "va_attn_bwd")) return e;
+        const dim3 grid_p((N + 255) / 256, B * H);
+        hipLaunchKernelGGL(attn_bwd_dkv64_kernel<false>, grid_p, dim3(256), LDS_P, stream, q, k, v, d_o, aux, dk, dv, N, H, ld, ldo,
+                           lddq, c, scale, (float*)nullptr);
+        VA_CHECK_LAUNCH("va_attn_bwd(dkv64)");
+        return VA_OK;
+    }
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, RAGGED_DKV, DROP, BITS>), grid, dim3(256), LDS_DKV, stream, q, k, v, d_o, aux, delta,
                        dk, dv, N, H, ld, ldo, lddq, c, scale, drop, mask);
     VA_CHECK_LAUNCH("va_attn_bwd(dkv)");
