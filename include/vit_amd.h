@@ -274,6 +274,23 @@ int va_dwconv1d_causal_silu(const float* x, const float* w, const float* bias, f
 int va_gate_layernorm_fwd(const float* o, const float* gate, const float* g, const float* gamma, const float* beta,
                           void* y_bf16, int64_t M, int64_t D, float eps, va_stream_t stream);
 
+/* The two kernels above for operands that are column blocks of ONE bf16 projection output: the layer's q, k, v and g
+ * projections (swm:484-500, 515) computed as a single GEMM against the row-wise concatenation of their weights give a
+ * bf16 matrix [B*L, 5 * 1024]; these entry points read a 1024-wide block of it in place.
+ * va_dwconv1d_causal_silu_bf16: x bf16, row (b, t) at x + (b*L + t) * ldx, C = 1024 channels; f32 out [B, L, C];
+ * otherwise as va_dwconv1d_causal_silu.  va_gate_layernorm_fwd_g16: g bf16 with rows ldg elements apart; o and gate
+ * f32 [M, D] contiguous; otherwise as va_gate_layernorm_fwd. */
+int va_dwconv1d_causal_silu_bf16(const void* x_bf16, int64_t ldx, const float* w, const float* bias, float* out, int64_t B,
+                                 int64_t L, int64_t C, int normalize, va_stream_t stream);
+int va_gate_layernorm_fwd_g16(const float* o, const float* gate, const void* g_bf16, int64_t ldg, const float* gamma,
+                              const float* beta, void* y_bf16, int64_t M, int64_t D, float eps, va_stream_t stream);
+
+/* The layer's two per-head gates, alpha = sigmoid(x @ wa^T) and beta = sigmoid(x @ wb^T) (swm:448-449, 494-495; the
+ * projections have no bias): x f32 [M, D] contiguous, D = 1024; wa, wb f32 [H, D], H <= 8; alpha, beta f32 [M, H].
+ * f32 products and sums; a row's summation order does not depend on its position in the batch. */
+int va_delta_gates_fwd(const float* x, const float* wa, const float* wb, float* alpha, float* beta, int64_t M, int64_t D,
+                       int64_t H, va_stream_t stream);
+
 /* ---- input pipeline: the tensor side of the reference's per-frame transform (ToTensor + Normalize,
  * stage1_surgvu_pretraining.py:241-244, 279-286) ---------------------------------------------------------
  * frames: uint8 [B, T, H, W, 3] on the device -> out: f32 [B, 3, T, H, W], (u / 255 - mean[c]) / std[c]

@@ -148,6 +148,70 @@ def test_dwconv_silu_vs_oracle(env, B, L, C, norm):
     assert (out.cpu() - ref).abs().max().item() < 2e-6 * (1 if norm else 10)
 
 
+@pytest.mark.parametrize("B,L,norm", [(2, 1, True), (2, 7, True), (3, 50, False), (1, 131, True)])
+def test_dwconv_silu_on_a_column_block_of_a_bf16_matrix(env, B, L, norm):
+    """The layer's conv inputs are 1024-wide column blocks of one bf16 projection output [B*L, 5120] (swm:484-500):
+    the kernel reads block `blk` in place; against the oracle on the same (bf16-exact) numbers, and the rest of the
+    matrix is poison that must not leak in."""
+    ops, _ = env
+    C, blk = 1024, 2
+    x = R.hashed_uniform("t.dw16.x", (B, L, C), 2.0).bfloat16()
+    w = R.hashed_uniform("t.dw16.w", (C, 1, 4), 0.5)
+    bias = R.hashed_uniform("t.dw16.b", (C,), 0.1)
+    ref = R.dwconv1d_causal_silu(x.float(), w, bias, norm)
+    wide = torch.full((B * L, 5 * C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wide[:, blk * C:(blk + 1) * C] = x.view(B * L, C).cuda()
+    out = ops.dwconv1d_causal_silu_bf16(wide[:, blk * C:(blk + 1) * C], B, L, w.cuda(), bias.cuda(), norm)
+    assert out.shape == (B, L, C) and bool(torch.isfinite(out).all())
+    assert (out.cpu() - ref).abs().max().item() < 2e-6 * (1 if norm else 10)
+    # the f32 kernel on the same numbers: the same taps in the same order
+    same = ops.dwconv1d_causal_silu(x.float().cuda(), w.cuda(), bias.cuda(), False)
+    if not norm:
+        assert torch.equal(out, same)
+    with pytest.raises(Exception):
+        ops.dwconv1d_causal_silu_bf16(wide[:, 4:4 + C], B, L, w.cuda(), bias.cuda(), norm)      # 8-byte aligned block only
+
+
+@pytest.mark.parametrize("M,H", [(1, 8), (7, 8), (1030, 8), (513, 4), (66, 3)])
+def test_delta_gates_vs_torch(env, M, H):
+    """alpha = sigmoid(x a_proj^T), beta = sigmoid(x b_proj^T) (swm:494-495) against the f64 product, and a row's
+    result does not depend on which rows surround it."""
+    ops, _ = env
+    x = R.hashed_uniform("t.ab.x", (M, 1024), 2.0)
+    wa = R.hashed_uniform("t.ab.wa", (H, 1024), 0.06)
+    wb = R.hashed_uniform("t.ab.wb", (H, 1024), 0.06)
+    alpha, beta = ops.delta_gates_fwd(x.cuda(), wa.cuda(), wb.cuda())
+    assert alpha.shape == (M, H) and beta.shape == (M, H)
+    ref_a = torch.sigmoid(x.double() @ wa.double().t()).float()
+    ref_b = torch.sigmoid(x.double() @ wb.double().t()).float()
+    assert (alpha.cpu() - ref_a).abs().max().item() < 2e-6 and (beta.cpu() - ref_b).abs().max().item() < 2e-6
+    if M > 4:
+        perm = torch.randperm(M, generator=torch.Generator().manual_seed(M))
+        a2, b2 = ops.delta_gates_fwd(x[perm].contiguous().cuda(), wa.cuda(), wb.cuda())
+        assert torch.equal(a2.cpu(), alpha.cpu()[perm]) and torch.equal(b2.cpu(), beta.cpu()[perm])
+    with pytest.raises(Exception):
+        ops.delta_gates_fwd(x[:, :512].contiguous().cuda(), wa[:, :512].contiguous().cuda(), wb[:, :512].contiguous().cuda())
+
+
+@pytest.mark.parametrize("M", [1, 5, 1030])
+def test_gate_layernorm_with_g_as_a_bf16_column_block(env, M):
+    """g read in place from the bf16 projection output (row stride 5120): identical to the f32 entry point on the
+    same numbers."""
+    ops, _ = env
+    o = R.hashed_uniform("t.gl16.o", (M, 1024), 2.0).cuda()
+    gate = R.hashed_uniform("t.gl16.gate", (M, 1024), 1.5).cuda()
+    g = R.hashed_uniform("t.gl16.g", (M, 1024), 4.0).bfloat16()
+    gamma = R.hashed_uniform("t.gl16.gamma", (1024,), 0.5, 1.0).cuda()
+    beta = R.hashed_uniform("t.gl16.beta", (1024,), 0.3).cuda()
+    wide = torch.full((M, 5120), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wide[:, 4096:] = g.cuda()
+    out = torch.empty(M, 1024, dtype=torch.bfloat16, device="cuda")
+    ops.gate_layernorm_fwd(o, gate, wide[:, 4096:], gamma, beta, out, 1e-5)
+    want = torch.empty_like(out)
+    ops.gate_layernorm_fwd(o, gate, g.float().cuda(), gamma, beta, want, 1e-5)
+    assert torch.equal(out, want)
+
+
 @pytest.mark.parametrize("B,T,tpt,H", [(2, 4, 6, 8), (1, 9, 18, 8), (2, 5, 66, 16), (1, 16, 129, 8)])
 def test_block_causal_attention_vs_oracle(env, B, T, tpt, H):
     ops, _ = env

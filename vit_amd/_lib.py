@@ -69,6 +69,9 @@ SIGNATURES = {
     "va_gated_delta_seq": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "va_dwconv1d_causal_silu": (ci, [vp, vp, vp, vp, i64, i64, i64, ci, vp]),
     "va_gate_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, i64, i64, cf, vp]),
+    "va_dwconv1d_causal_silu_bf16": (ci, [vp, i64, vp, vp, vp, i64, i64, i64, ci, vp]),
+    "va_delta_gates_fwd": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    "va_gate_layernorm_fwd_g16": (ci, [vp, vp, vp, i64, vp, vp, vp, i64, i64, cf, vp]),
 }
 
 

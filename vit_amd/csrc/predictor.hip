@@ -372,12 +372,93 @@ void launch_dwconv_run(const float* x, const float* w, const float* bias, float*
                        bias, out, runs, L, normalize);
 }
 
+// The same arithmetic for 1024 channels read as bf16 from rows `ldx` elements apart -- a column block of the output of
+// ONE projection GEMM that serves q, k, v, the value gate and g together.  A lane owns 8 consecutive channels (one
+// 16-byte load per row) in each half of the row; RUN time steps per wave through the same sliding window; f32 results.
+template <int RUN>
+__global__ __launch_bounds__(256) void dwconv_silu_bf16_kernel(const bf16_t* __restrict__ X, int64_t ldx,
+                                                               const float* __restrict__ W, const float* __restrict__ BIAS,
+                                                               float* __restrict__ OUT, int64_t runs, int L, int normalize) {
+    constexpr int C = 1024;
+    const int lane = threadIdx.x & 63;
+    const int64_t run = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (run >= runs) return;
+    const int runs_per_seq = (L + RUN - 1) / RUN;
+    const int64_t b = run / runs_per_seq;
+    const int t0 = (int)(run % runs_per_seq) * RUN;
+    const bf16_t* xb = X + b * (int64_t)L * ldx;
+    float* ob = OUT + b * (int64_t)L * C;
+    float res[RUN][2][8];
+    float ss[RUN];
+#pragma unroll
+    for (int r = 0; r < RUN; ++r) ss[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int c0 = lane * 8 + 512 * m;
+        float bias[8];
+        *(f32x4_t*)bias = *(const f32x4_t*)(BIAS + c0);
+        *(f32x4_t*)(bias + 4) = *(const f32x4_t*)(BIAS + c0 + 4);
+        f32x4_t w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = *(const f32x4_t*)(W + (int64_t)(c0 + e) * 4);   // taps of channel c0+e
+        u32x4_t win[RUN + 3];                        // rows t0-3 .. t0+RUN-1 (zeros before the sequence start)
+#pragma unroll
+        for (int i = 0; i < RUN + 3; ++i) {
+            const int t = t0 - 3 + i;
+            win[i] = (t >= 0 && t < L) ? *(const u32x4_t*)(xb + (int64_t)t * ldx + c0) : (u32x4_t){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int r = 0; r < RUN; ++r) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc = bias[e];
+#pragma unroll
+                for (int tap = 0; tap < 4; ++tap) {      // tap i multiplies x[t - 3 + i]; same order as the f32 kernels
+                    if (t0 + r - (3 - tap) < 0) continue;
+                    const uint32_t pair = win[r + tap][e >> 1];
+                    const float xv = __uint_as_float((e & 1) ? (pair & 0xffff0000u) : (pair << 16));
+                    acc = fmaf(w[e][tap], xv, acc);
+                }
+                acc = acc / (1.0f + __expf(-acc));     // SiLU
+                ss[r] = fmaf(acc, acc, ss[r]);
+                res[r][m][e] = acc;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RUN; ++r) {
+        if (t0 + r >= L) break;
+        float inv = 1.0f;
+        if (normalize) {
+            float tot = ss[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+            inv = 1.0f / fmaxf(sqrtf(tot), 1e-12f);   // F.normalize: x / max(||x||, eps)
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float* dst = ob + (int64_t)(t0 + r) * C + lane * 8 + 512 * m;
+            f32x4_t lo = {res[r][m][0], res[r][m][1], res[r][m][2], res[r][m][3]};
+            f32x4_t hi = {res[r][m][4], res[r][m][5], res[r][m][6], res[r][m][7]};
+            if (normalize) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] *= inv; hi[e] *= inv; }
+            }
+            *(f32x4_t*)dst = lo;
+            *(f32x4_t*)(dst + 4) = hi;
+        }
+    }
+}
+
 // Output stage of the memory layer (swm:511-519 up to the projection): row = (o * gate) * silu(g), then
 // LayerNorm over the 1024-wide row, written as the bf16 operand of the output projection.  One wave per row,
 // 16 elements per lane.
 constexpr int GLN_D = 1024;
+// G16: g is bf16 with rows `ldg` elements apart (a column block of the merged projection GEMM's output)
+template <bool G16>
 __global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ o, const float* __restrict__ gate,
-                                                      const float* __restrict__ g, const float* __restrict__ gamma,
+                                                      const void* __restrict__ g_any, int64_t ldg,
+                                                      const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ y, int64_t M,
                                                       float eps) {
     const int lane = threadIdx.x & 63;
@@ -388,7 +469,15 @@ __global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t at = row * GLN_D + q * 256 + lane * 4;
-        const f32x4_t ov = *(const f32x4_t*)(o + at), gv = *(const f32x4_t*)(gate + at), xv = *(const f32x4_t*)(g + at);
+        const f32x4_t ov = *(const f32x4_t*)(o + at), gv = *(const f32x4_t*)(gate + at);
+        f32x4_t xv;
+        if (G16) {
+            const u32x2_t pk = *(const u32x2_t*)((const bf16_t*)g_any + row * ldg + q * 256 + lane * 4);
+            xv = (f32x4_t){__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u), __uint_as_float(pk[1] << 16),
+                           __uint_as_float(pk[1] & 0xffff0000u)};
+        } else {
+            xv = *(const f32x4_t*)((const float*)g_any + at);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float silu = xv[j] / (1.0f + __expf(-xv[j]));
@@ -421,7 +510,93 @@ __global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ 
     }
 }
 
+// The memory layer's two per-head gate projections (swm:494-495: alpha = sigmoid(a_proj(x)), beta = sigmoid(b_proj(x)),
+// no bias): x f32 [M, 1024]; WA, WB f32 [H, 1024], H <= 8.  The 2H weight rows live in LDS (rows beyond 2H are zero);
+// a wave takes 4 rows of x at a time, every lane forming its 16-column share of the 4 x 16 dot products, and a
+// halving exchange (32 + 16 + ... + 1 = 63 cross-lane moves instead of 64 six-step butterflies) leaves lane l with the
+// complete sum of row l / 16, output l % 16.  The summation order of a row does not depend on where the row lies.
+constexpr int ABG_D = 1024, ABG_ROWS = 4;
+__global__ __launch_bounds__(256) void ab_gate_kernel(const float* __restrict__ X, const float* __restrict__ WA,
+                                                      const float* __restrict__ WB, float* __restrict__ ALPHA,
+                                                      float* __restrict__ BETA, int64_t M, int H) {
+    extern __shared__ __align__(16) float abw[];          // [16][1024]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 16 * ABG_D / 4; i += 256) {
+        const int o = i / (ABG_D / 4), c = (i % (ABG_D / 4)) * 4;
+        f32x4_t w = {0.f, 0.f, 0.f, 0.f};
+        if (o < H) w = *(const f32x4_t*)(WA + (int64_t)o * ABG_D + c);
+        else if (o < 2 * H) w = *(const f32x4_t*)(WB + (int64_t)(o - H) * ABG_D + c);
+        *(f32x4_t*)(abw + o * ABG_D + c) = w;
+    }
+    __syncthreads();
+    const int64_t groups = (M + ABG_ROWS - 1) / ABG_ROWS;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = grp * ABG_ROWS;
+        float acc[ABG_ROWS * 16];
+#pragma unroll
+        for (int i = 0; i < ABG_ROWS * 16; ++i) acc[i] = 0.f;
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            f32x4_t xv[ABG_ROWS];
+#pragma unroll
+            for (int r = 0; r < ABG_ROWS; ++r) {
+                const int64_t row = row0 + r < M ? row0 + r : M - 1;
+                xv[r] = *(const f32x4_t*)(X + row * ABG_D + q * 256 + lane * 4);
+            }
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                const f32x4_t w = *(const f32x4_t*)(abw + o * ABG_D + q * 256 + lane * 4);
+#pragma unroll
+                for (int r = 0; r < ABG_ROWS; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[r * 16 + o] = fmaf(xv[r][e], w[e], acc[r * 16 + o]);
+            }
+        }
+        // halving exchange: after the step with offset `off` a lane keeps the half of its values whose index has
+        // the same `off`-bit as the lane id
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const bool upper = (lane & off) != 0;
+#pragma unroll
+            for (int i = 0; i < off; ++i) {
+                const float keep = upper ? acc[i + off] : acc[i];
+                const float send = upper ? acc[i] : acc[i + off];
+                acc[i] = keep + __shfl_xor(send, off);
+            }
+        }
+        const int r = lane >> 4, o = lane & 15;
+        const float y = 1.0f / (1.0f + __expf(-acc[0]));
+        if (row0 + r < M) {
+            if (o < H) ALPHA[(row0 + r) * H + o] = y;
+            else if (o < 2 * H) BETA[(row0 + r) * H + (o - H)] = y;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int va_delta_gates_fwd(const float* x, const float* wa, const float* wb, float* alpha, float* beta, int64_t M,
+                                  int64_t D, int64_t H, hipStream_t stream) {
+    VA_CHECK_ARG(x && wa && wb && alpha && beta, "va_delta_gates_fwd: null operand");
+    VA_CHECK_ARG(D == ABG_D, "va_delta_gates_fwd: width %lld not supported (1024)", (long long)D);
+    VA_CHECK_ARG(H >= 1 && H <= 8, "va_delta_gates_fwd: %lld heads not supported (1..8)", (long long)H);
+    VA_CHECK_ARG(M > 0 && M < (1ll << 33), "va_delta_gates_fwd: row count out of range");
+    VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)wa | (uintptr_t)wb) % 16 == 0, "va_delta_gates_fwd: misaligned operand");
+    static bool lds_ok = false;
+    constexpr int lds = 16 * ABG_D * 4;
+    if (!lds_ok) {
+        if (hipFuncSetAttribute((const void*)ab_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            va_set_error("va_delta_gates_fwd: cannot reserve %d bytes of LDS", lds);
+            return VA_ERR_LAUNCH;
+        }
+        lds_ok = true;
+    }
+    const int64_t blocks_wanted = (M + 4 * ABG_ROWS - 1) / (4 * ABG_ROWS);
+    const unsigned grid = (unsigned)(blocks_wanted < 512 ? blocks_wanted : 512);
+    hipLaunchKernelGGL(ab_gate_kernel, dim3(grid), dim3(256), lds, stream, x, wa, wb, alpha, beta, M, (int)H);
+    VA_CHECK_LAUNCH("va_delta_gates_fwd");
+    return VA_OK;
+}
 
 extern "C" int va_gated_delta_seq(const float* q, const float* k, const float* v, const float* alpha, const float* beta,
                                   const float* state_in, float* out, float* state_out, int64_t B, int64_t L, int64_t H,
@@ -472,8 +647,41 @@ extern "C" int va_gate_layernorm_fwd(const float* o, const float* gate, const fl
     VA_CHECK_ARG(M > 0 && M < (1ll << 33), "va_gate_layernorm_fwd: row count out of range");
     VA_CHECK_ARG(((uintptr_t)o | (uintptr_t)gate | (uintptr_t)g | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y_bf16) % 16 == 0,
                  "va_gate_layernorm_fwd: misaligned operand");
-    hipLaunchKernelGGL(gate_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, o, gate, g, gamma, beta,
-                       (bf16_t*)y_bf16, M, eps);
+    hipLaunchKernelGGL(gate_ln_kernel<false>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, o, gate, (const void*)g,
+                       (int64_t)GLN_D, gamma, beta, (bf16_t*)y_bf16, M, eps);
     VA_CHECK_LAUNCH("va_gate_layernorm_fwd");
+    return VA_OK;
+}
+
+extern "C" int va_gate_layernorm_fwd_g16(const float* o, const float* gate, const void* g_bf16, int64_t ldg,
+                                         const float* gamma, const float* beta, void* y_bf16, int64_t M, int64_t D, float eps,
+                                         hipStream_t stream) {
+    VA_CHECK_ARG(o && gate && g_bf16 && gamma && beta && y_bf16, "va_gate_layernorm_fwd_g16: null operand");
+    VA_CHECK_ARG(D == GLN_D, "va_gate_layernorm_fwd_g16: width %lld not supported (1024)", (long long)D);
+    VA_CHECK_ARG(M > 0 && M < (1ll << 33), "va_gate_layernorm_fwd_g16: row count out of range");
+    VA_CHECK_ARG(ldg >= D && ldg % 4 == 0, "va_gate_layernorm_fwd_g16: row stride of g must be >= D and keep 8-byte alignment");
+    VA_CHECK_ARG(((uintptr_t)o | (uintptr_t)gate | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y_bf16) % 16 == 0 &&
+                     (uintptr_t)g_bf16 % 8 == 0,
+                 "va_gate_layernorm_fwd_g16: misaligned operand");
+    hipLaunchKernelGGL(gate_ln_kernel<true>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, o, gate, g_bf16, ldg, gamma,
+                       beta, (bf16_t*)y_bf16, M, eps);
+    VA_CHECK_LAUNCH("va_gate_layernorm_fwd_g16");
+    return VA_OK;
+}
+
+extern "C" int va_dwconv1d_causal_silu_bf16(const void* x_bf16, int64_t ldx, const float* w, const float* bias, float* out,
+                                            int64_t B, int64_t L, int64_t C, int normalize, hipStream_t stream) {
+    VA_CHECK_ARG(x_bf16 && w && bias && out, "va_dwconv1d_causal_silu_bf16: null operand");
+    VA_CHECK_ARG(B > 0 && L > 0, "va_dwconv1d_causal_silu_bf16: empty problem");
+    VA_CHECK_ARG(C == 1024, "va_dwconv1d_causal_silu_bf16: C=%lld not supported (1024)", (long long)C);
+    VA_CHECK_ARG(ldx >= C && ldx % 8 == 0, "va_dwconv1d_causal_silu_bf16: row stride must be >= C and keep 16-byte alignment");
+    VA_CHECK_ARG(((uintptr_t)x_bf16 | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out) % 16 == 0,
+                 "va_dwconv1d_causal_silu_bf16: misaligned operand");
+    VA_CHECK_ARG(B * L < (1ll << 33) && L < (1ll << 31), "va_dwconv1d_causal_silu_bf16: problem too large");
+    constexpr int RUN = 4;
+    const int64_t runs = B * ((L + RUN - 1) / RUN);
+    hipLaunchKernelGGL((dwconv_silu_bf16_kernel<RUN>), dim3((unsigned)((runs + 3) / 4)), dim3(256), 0, stream,
+                       (const bf16_t*)x_bf16, ldx, w, bias, out, runs, (int)L, normalize);
+    VA_CHECK_LAUNCH("va_dwconv1d_causal_silu_bf16");
     return VA_OK;
 }

@@ -117,6 +117,22 @@ class WeightCache:
             if bbuf is not None:
                 self._bwd[name] = (*key, bbuf)
 
+    def fwd_cat(self, name: str, params) -> torch.Tensor:
+        """bf16 copy of the row-wise concatenation of several [*, K] weights (one GEMM then serves all of them)."""
+        key = tuple(self._key(p) for p in params)
+        ent = self._fwd.get(name)
+        if ent is None or ent[0] != key:
+            rows = sum(p.shape[0] for p in params)
+            buf = ent[2] if ent is not None and ent[2].shape[0] == rows else torch.empty(
+                rows, params[0].shape[1], dtype=BF16, device=params[0].device)
+            at = 0
+            for p in params:
+                ops.cast_bf16(p.detach(), buf[at:at + p.shape[0]])
+                at += p.shape[0]
+            ent = (key, 0, buf)
+            self._fwd[name] = ent
+        return ent[2]
+
     def fwd(self, name: str, p: torch.Tensor) -> torch.Tensor:
         ent = self._fwd.get(name)
         if ent is None or (ent[0], ent[1]) != self._key(p):

@@ -415,17 +415,57 @@ def dwconv1d_causal_silu(x, weight, bias, normalize: bool):
 
 
 def gate_layernorm_fwd(o, gate, g, gamma, beta, out, eps: float = 1e-5):
-    """out (bf16 [M,D]) = LayerNorm((o * gate) * silu(g)); o, gate, g f32 [M,D] contiguous (swm:511-519)."""
+    """out (bf16 [M,D]) = LayerNorm((o * gate) * silu(g)); o, gate f32 [M,D] contiguous; g f32 [M,D] contiguous, or bf16
+    [M,D] with any row stride (a column block of the merged projection output) (swm:511-519)."""
     M, D = o.shape
-    for name, x in (("o", o), ("gate", gate), ("g", g)):
+    for name, x in (("o", o), ("gate", gate)):
         _need(x, F32, name)
         if tuple(x.shape) != (M, D) or not x.is_contiguous():
             raise ValueError(f"gate_layernorm_fwd: {name} must be contiguous [M,D]")
     _need(gamma, F32, "gamma"); _need(beta, F32, "beta"); _need(out, BF16, "out")
     if tuple(out.shape) != (M, D) or not out.is_contiguous() or gamma.numel() != D or beta.numel() != D:
         raise ValueError("gate_layernorm_fwd: inconsistent shapes")
+    if tuple(g.shape) != (M, D):
+        raise ValueError("gate_layernorm_fwd: g must be [M,D]")
+    if g.dtype == BF16:
+        _need(g, BF16, "g")
+        check(_lib.load().va_gate_layernorm_fwd_g16(_p(o), _p(gate), _p(g), _ld(g), _p(gamma), _p(beta), _p(out), M, D, eps,
+                                                    _stream()), "va_gate_layernorm_fwd_g16")
+        return out
+    _need(g, F32, "g")
+    if not g.is_contiguous():
+        raise ValueError("gate_layernorm_fwd: an f32 g must be contiguous [M,D]")
     check(_lib.load().va_gate_layernorm_fwd(_p(o), _p(gate), _p(g), _p(gamma), _p(beta), _p(out), M, D, eps, _stream()),
           "va_gate_layernorm_fwd")
+    return out
+
+
+def delta_gates_fwd(x2d, wa, wb):
+    """alpha, beta = sigmoid(x @ wa^T), sigmoid(x @ wb^T): x f32 [M, 1024]; wa, wb f32 [H, 1024] -> two f32 [M, H]
+    (swm:494-495)."""
+    _need(x2d, F32, "x"); _need(wa, F32, "wa"); _need(wb, F32, "wb")
+    M, D = x2d.shape
+    H = wa.shape[0]
+    if tuple(wa.shape) != (H, D) or tuple(wb.shape) != (H, D) or not (x2d.is_contiguous() and wa.is_contiguous()
+                                                                      and wb.is_contiguous()):
+        raise ValueError("delta_gates_fwd: inconsistent shapes")
+    alpha = torch.empty(M, H, dtype=F32, device=x2d.device)
+    beta = torch.empty(M, H, dtype=F32, device=x2d.device)
+    check(_lib.load().va_delta_gates_fwd(_p(x2d), _p(wa), _p(wb), _p(alpha), _p(beta), M, D, H, _stream()),
+          "va_delta_gates_fwd")
+    return alpha, beta
+
+
+def dwconv1d_causal_silu_bf16(x2d, B: int, L: int, weight, bias, normalize: bool):
+    """x2d bf16 [B*L, 1024] with any row stride (a column block of the merged projection output), rows ordered (b, t);
+    weight f32 [C,1,4] or [C,4]; bias [C] -> f32 [B, L, C] = silu(causal conv) [, row-L2-normalised]."""
+    _need(x2d, BF16, "x"); _need(weight, F32, "weight"); _need(bias, F32, "bias")
+    M, C = x2d.shape
+    if M != B * L or weight.numel() != 4 * C or bias.numel() != C or not weight.is_contiguous():
+        raise ValueError("dwconv1d_causal_silu_bf16: inconsistent shapes")
+    out = torch.empty(B, L, C, dtype=F32, device=x2d.device)
+    check(_lib.load().va_dwconv1d_causal_silu_bf16(_p(x2d), _ld(x2d), _p(weight), _p(bias), _p(out), B, L, C,
+                                                   int(bool(normalize)), _stream()), "va_dwconv1d_causal_silu_bf16")
     return out
 
 

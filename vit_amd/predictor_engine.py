@@ -1,10 +1,10 @@
 """Inference launch schedule of one predictor block (HybridPredictorBlock.forward, swm:975-997) on the HIP
 kernels: LayerNorm -> in-proj GEMM (+bias) -> block-causal attention -> out-proj GEMM (+bias +residual) ->
-[gated delta memory: projection GEMMs, causal conv + SiLU (+normalise), delta-rule recurrence, gating +
-LayerNorm, o-proj GEMM (+residual)] -> LayerNorm -> fc1 (+bias, GELU) -> fc2 (+bias +residual).
+[gated delta memory: one projection GEMM for q/k/v/g, causal conv + SiLU (+normalise), delta-rule recurrence,
+gating + LayerNorm, o-proj GEMM (+residual)] -> LayerNorm -> fc1 (+bias, GELU) -> fc2 (+bias +residual).
 
 Same numeric scheme as the encoder: f32 residual stream and statistics, bf16 GEMM/attention operands with f32
-accumulation.  The two 8-wide gate projections (a_proj, b_proj) stay a torch product.
+accumulation; the two 8-wide gate projections (a_proj, b_proj) are f32 dot products.
 """
 from __future__ import annotations
 
@@ -24,7 +24,8 @@ def block_supported(blk, x: torch.Tensor) -> bool:
     any other predictor size takes the torch formulation."""
     D = x.shape[-1]
     H = blk.spatial_attn.num_heads
-    if blk.use_deltanet and blk.temporal_layer.num_heads * blk.temporal_layer.head_dim != 1024:
+    if blk.use_deltanet and (blk.temporal_layer.num_heads * blk.temporal_layer.head_dim != 1024
+                             or blk.temporal_layer.num_heads > 8):
         return False
     return (D == 1024 and D // H in (64, 128) and blk.spatial_attn.in_proj_bias is not None
             and blk.spatial_attn._qkv_same_embed_dim)
@@ -61,29 +62,29 @@ def block_forward(blk, x: torch.Tensor, tokens_per_timestep: int, state: Optiona
         Hd, Dh = t.num_heads, t.head_dim
         inner = Hd * Dh
         xb = ops.cast_bf16(x_mid)
-        # v_proj's two halves (the value and its gate, swm:500) as two GEMMs and two convolutions, so that each half
-        # is a contiguous operand of the kernels that follow
-        wv = wc.fwd("v_proj", t.v_proj.weight)
+        # q, k, v (value half and gate half, swm:500) and g as ONE product against the stacked weights; every kernel
+        # that follows reads its 1024-wide column block of the bf16 result in place
+        proj = new(5 * inner, BF16)
+        ops.gemm_nt(xb, wc.fwd_cat("qkvg_proj", (t.q_proj.weight, t.k_proj.weight, t.v_proj.weight, t.g_proj.weight)),
+                    ops.EPI_BF16, proj)
         conv_w, conv_b = t.v_conv1d.weight.detach().reshape(2 * inner, 4), t.v_conv1d.bias.detach()
-        lin = {}
-        for name, w in (("q", wc.fwd("q_proj", t.q_proj.weight)), ("k", wc.fwd("k_proj", t.k_proj.weight)),
-                        ("v", wv[:inner]), ("gate", wv[inner:]), ("g", wc.fwd("g_proj", t.g_proj.weight))):
-            lin[name] = new(inner, F32)
-            ops.gemm_nt(xb, w, ops.EPI_F32, lin[name])
-        # the two 8-wide gate projections as one product
-        ab = torch.sigmoid(x_mid @ torch.cat([t.a_proj.weight.detach(), t.b_proj.weight.detach()]).t())
-        alpha, beta = ab[:, :Hd].contiguous().view(B, L, Hd), ab[:, Hd:].contiguous().view(B, L, Hd)
-        q = ops.dwconv1d_causal_silu(lin["q"].view(B, L, inner), t.q_conv1d.weight.detach(), t.q_conv1d.bias.detach(), True)
-        k = ops.dwconv1d_causal_silu(lin["k"].view(B, L, inner), t.k_conv1d.weight.detach(), t.k_conv1d.bias.detach(), True)
-        v = ops.dwconv1d_causal_silu(lin["v"].view(B, L, inner), conv_w[:inner], conv_b[:inner], False)
-        v_gate = ops.dwconv1d_causal_silu(lin["gate"].view(B, L, inner), conv_w[inner:], conv_b[inner:], False)
+        alpha, beta = ops.delta_gates_fwd(x_mid, t.a_proj.weight.detach(), t.b_proj.weight.detach())
+        alpha, beta = alpha.view(B, L, Hd), beta.view(B, L, Hd)
+
+        def col(i):
+            return proj[:, i * inner:(i + 1) * inner]
+
+        q = ops.dwconv1d_causal_silu_bf16(col(0), B, L, t.q_conv1d.weight.detach(), t.q_conv1d.bias.detach(), True)
+        k = ops.dwconv1d_causal_silu_bf16(col(1), B, L, t.k_conv1d.weight.detach(), t.k_conv1d.bias.detach(), True)
+        v = ops.dwconv1d_causal_silu_bf16(col(2), B, L, conv_w[:inner], conv_b[:inner], False)
+        v_gate = ops.dwconv1d_causal_silu_bf16(col(3), B, L, conv_w[inner:], conv_b[inner:], False)
         out, new_state = ops.gated_delta_seq(q.view(B, L, Hd, Dh), k.view(B, L, Hd, Dh), v.view(B, L, Hd, Dh), alpha, beta,
                                              None if state is None else state.detach().contiguous())
         del q, k, v
         on = new(inner, BF16)
-        ops.gate_layernorm_fwd(out.view(M, inner), v_gate.view(M, inner), lin["g"], t.o_norm.weight.detach(),
+        ops.gate_layernorm_fwd(out.view(M, inner), v_gate.view(M, inner), col(4), t.o_norm.weight.detach(),
                                t.o_norm.bias.detach(), on, t.o_norm.eps)
-        del lin, out, v_gate
+        del proj, out, v_gate
         x_dn = new(D, F32)
         ops.gemm_nt(on, wc.fwd("o_proj", t.o_proj.weight), ops.EPI_F32, x_dn, resid=x_mid)
         x_mid = x_dn
@@ -94,3 +95,56 @@ def block_forward(blk, x: torch.Tensor, tokens_per_timestep: int, state: Optiona
     x_out = new(D, F32)
     ops.gemm_nt(act, wc.fwd("fc2", blk.mlp[2].weight), ops.EPI_F32, x_out, bias=blk.mlp[2].bias.detach(), resid=x_mid)
     return x_out.view(B, L, D), new_state
+
+
+def linear(x2: torch.Tensor, lin, wc: WeightCache, name: str, gelu: bool = False) -> torch.Tensor:
+    """nn.Linear on rows x2 ([M, K], f32 or bf16) through the GEMM kernel: f32 [M, N], or with gelu=True the bf16
+    GELU of it (the operand of the next Linear)."""
+    xb = x2 if x2.dtype == BF16 else ops.cast_bf16(x2.contiguous())
+    M, N = xb.shape[0], lin.weight.shape[0]
+    bias = None if lin.bias is None else lin.bias.detach()
+    out = torch.empty(M, N, dtype=BF16 if gelu else F32, device=xb.device)
+    if gelu:
+        if bias is None:
+            bias = torch.zeros(N, dtype=F32, device=xb.device)
+        return ops.gemm_nt(xb, wc.fwd(name, lin.weight), ops.EPI_GELU_ONLY, out, bias=bias)
+    return ops.gemm_nt(xb, wc.fwd(name, lin.weight), ops.EPI_F32, out, bias=bias)
+
+
+def linear_supported(lin) -> bool:
+    return isinstance(lin, torch.nn.Linear) and lin.weight.shape[0] % 128 == 0 and lin.weight.shape[1] % 64 == 0
+
+
+def sequential_forward(seq, x: torch.Tensor, wc: WeightCache, name: str) -> torch.Tensor:
+    """Inference forward of an nn.Sequential of LayerNorm / Linear / GELU / Dropout / anything else over the last
+    dimension of x (f32): every Linear whose sides the GEMM kernel takes runs there (a following GELU inside its
+    epilogue), a 1024-wide LayerNorm on the LayerNorm kernel, the rest (the 7-wide output layers, Softplus) in torch."""
+    lead = x.shape[:-1]
+    cur = x.reshape(-1, x.shape[-1])
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Dropout):
+            i += 1
+            continue
+        if linear_supported(m):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.GELU) and mods[i + 1].approximate == "none"
+            cur = linear(cur, m, wc, f"{name}.{i}", gelu=fuse)
+            i += 2 if fuse else 1
+            continue
+        if cur.dtype == BF16:
+            cur = cur.float()
+        if (isinstance(m, torch.nn.LayerNorm) and cur.shape[-1] == 1024 and m.elementwise_affine and m.bias is not None
+                and i + 1 < len(mods) and linear_supported(mods[i + 1])):
+            M = cur.shape[0]
+            ln = torch.empty(M, 1024, dtype=BF16, device=cur.device)
+            mean, rstd = torch.empty(M, dtype=F32, device=cur.device), torch.empty(M, dtype=F32, device=cur.device)
+            ops.layernorm_fwd(cur.contiguous(), m.weight.detach(), m.bias.detach(), ln, mean, rstd, m.eps)
+            cur = ln
+        else:
+            cur = m(cur)
+        i += 1
+    if cur.dtype == BF16:
+        cur = cur.float()
+    return cur.reshape(*lead, cur.shape[-1])

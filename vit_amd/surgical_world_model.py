@@ -563,9 +563,7 @@ class HybridPredictorBlock(nn.Module):
         tpt = 0 if attn_mask is None else getattr(attn_mask, "tokens_per_timestep", -1)
         if (_hip_inference(x, self) and tpt >= 0 and (tpt == 0 or x.shape[1] % tpt == 0)
                 and predictor_engine.block_supported(self, x)):
-            if getattr(self, "_operand_cache", None) is None:
-                self._operand_cache = WeightCache()
-            return predictor_engine.block_forward(self, x, tpt, state, self._operand_cache)
+            return predictor_engine.block_forward(self, x, tpt, state, _own_cache(self))
         if not _hip_inference(x, self):
             _note_torch_path(x, "HybridPredictorBlock.forward")
         x = x + self._masked_attention(self.norm1(x), attn_mask)
@@ -636,14 +634,24 @@ class AutoregressivePredictor(nn.Module):
         seq = x
         states = [None] * len(predictor_blocks) if predictor_blocks is not None else None
         results: List[Dict[str, torch.Tensor]] = []
+        if _hip_inference(x, self):
+            # every head's Linear layers on the GEMM kernel (the 7-wide output layers stay torch products)
+            wc = _own_cache(self)
+
+            def run(seq_module, name, t):
+                return predictor_engine.sequential_forward(seq_module, t, wc, name)
+        else:
+            def run(seq_module, name, t):
+                return seq_module(t)
         for h in range(predict_horizon):
             patches = seq[:, -tokens_per_timestep:][:, :self.num_patch_tokens]
-            next_patches = self.spatial_predictor(patches)
+            next_patches = run(self.spatial_predictor, "spatial_predictor", patches)
             ctx = self.spatial_pooling(patches)
-            act, sta = self.action_predictor(ctx), self.state_predictor(ctx)
-            results.append({"features": self.to_encoder_features(next_patches.mean(dim=1)), "action": act, "state": sta,
-                            "action_uncertainty": self.action_uncertainty(ctx),
-                            "state_uncertainty": self.state_uncertainty(ctx)})
+            act, sta = run(self.action_predictor, "action_predictor", ctx), run(self.state_predictor, "state_predictor", ctx)
+            results.append({"features": run(self.to_encoder_features, "to_encoder_features", next_patches.mean(dim=1)),
+                            "action": act, "state": sta,
+                            "action_uncertainty": run(self.action_uncertainty, "action_uncertainty", ctx),
+                            "state_uncertainty": run(self.state_uncertainty, "state_uncertainty", ctx)})
             if h == predict_horizon - 1:
                 break
             nxt_a = future_actions[:, h] if future_actions is not None and h < future_actions.shape[1] else act
@@ -733,7 +741,11 @@ class SurgicalActionConditionedWorldModel(nn.Module):
             enc = self.encoder(video)
         pooled_now = enc.mean(dim=1)
         Tp, tpf = self.encoder.tubelet_embed.num_temporal_patches, self.tokens_per_frame
-        tokens = self.video_proj(enc).view(B, Tp, tpf, -1)
+        if _hip_inference(enc, self.video_proj) and predictor_engine.linear_supported(self.video_proj):
+            tokens = predictor_engine.linear(enc.reshape(-1, enc.shape[-1]), self.video_proj, _own_cache(self), "video_proj")
+            tokens = tokens.view(B, Tp, tpf, -1)
+        else:
+            tokens = self.video_proj(enc).view(B, Tp, tpf, -1)
         a_emb, s_emb = self.action_state_embed(actions, states, target_temporal_length=Tp,
                                                timestep_indices=torch.arange(Tp, device=actions.device))
         x = self.interleave_tokens(tokens, a_emb, s_emb)
