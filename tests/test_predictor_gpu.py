@@ -285,6 +285,24 @@ def test_predictor_block_kernel_path_equals_torch_formulation(env, heads):
     assert rel(y_next, y_t2.detach()) < REL_TOL and rel(st_next, st_t2.detach()) < REL_TOL
 
 
+def test_pooling_and_heads_kernel_path_equals_torch_formulation(env):
+    """SpatialAttentionPooling (swm:1035-1080) and the per-horizon heads (swm:1083-1150) without an autograd graph run
+    their Linear layers on the GEMM kernel (bf16 operands); with one, torch's f32 layers.  Same numbers to the bf16
+    tolerance."""
+    _, swm = env
+    torch.manual_seed(11)
+    ar = swm.AutoregressivePredictor(1024, 1024, num_patch_tokens=16).eval().cuda()
+    x = R.hashed_uniform("t.pool.x", (3, 2 * 18, 1024), 1.0).cuda()
+    with torch.no_grad():
+        fast = ar(x, 18, predict_horizon=1)[0]
+        pooled = ar.spatial_pooling(x[:, -18:][:, :16])
+    slow = ar(x, 18, predict_horizon=1)[0]                       # grad mode on, trainable parameters: torch layers
+    pooled_t = ar.spatial_pooling(x[:, -18:][:, :16])
+    assert rel(pooled, pooled_t.detach()) < REL_TOL
+    for k in fast:
+        assert fast[k].shape == slow[k].shape and rel(fast[k], slow[k].detach()) < REL_TOL, k
+
+
 def test_world_model_forward_matches_reference_vectors(env, gold):
     _, swm = env
     torch.manual_seed(0)

@@ -599,7 +599,24 @@ class SpatialAttentionPooling(nn.Module):
 
     def forward(self, patch_tokens):
         B = patch_tokens.shape[0]
-        pooled, _ = self.attention(self.queries.unsqueeze(0).expand(B, -1, -1), patch_tokens, patch_tokens)
+        a = self.attention
+        E, H = a.embed_dim, a.num_heads
+        if (_hip_inference(patch_tokens, self) and a._qkv_same_embed_dim and a.in_proj_bias is not None and E % 128 == 0
+                and not (self.training and a.dropout > 0)):
+            # the key/value projection of every patch token is the one sizeable product here: on the GEMM kernel;
+            # the four queries, their 4 x n scores and the output projection of 4 rows per clip stay torch (f32)
+            n = patch_tokens.shape[1]
+            w, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
+            wc = _own_cache(self)
+            kv = torch.empty(B * n, 2 * E, dtype=torch.float32, device=patch_tokens.device)
+            ops.gemm_nt(ops.cast_bf16(patch_tokens.reshape(B * n, E).contiguous()), wc.fwd("in_proj", a.in_proj_weight)[E:],
+                        ops.EPI_F32, kv, bias=b[E:].contiguous())
+            q = F.linear(self.queries.detach(), w[:E], b[:E]).view(1, -1, H, E // H).transpose(1, 2).expand(B, -1, -1, -1)
+            k = kv[:, :E].view(B, n, H, E // H).transpose(1, 2)
+            v = kv[:, E:].view(B, n, H, E // H).transpose(1, 2)
+            o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, -1, E)
+            return self.norm(a.out_proj(o)).reshape(B, -1)
+        pooled, _ = a(self.queries.unsqueeze(0).expand(B, -1, -1), patch_tokens, patch_tokens)
         return self.norm(pooled).reshape(B, -1)
 
 
