@@ -6,6 +6,9 @@
 //   dbg 1  no operand loads in the main loop            dbg 2  no LDS fragment reads
 //   dbg 3  no stage barrier                             dbg 5  correct results + s_memtime / s_memrealtime stamps
 //   dbg 6  operands fetched as whole lines into registers and dropped       dbg 7  the same + one ds_write_b128 each
+//   dbg 8  stamps + epilogue without its stores         dbg 9  stamps + static tile hand-out (no ticket atomics)
+//   dbg 10 stamps + epilogue that stores zeros without reading the accumulators
+//   dbg 11-16  as 10 with other store shapes (see the kernel)
 // Build (done by the tools that use it): hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared
 //                                        -I vit_amd/csrc -I include tools/gemm_nt_debug.hip -o tools/libva_gemm_debug.so
 #include <cstdarg>
@@ -28,7 +31,7 @@ extern "C" const char* va_dbg_last_error(void) { return dbg_error; }
 extern "C" int va_dbg_gemm_nt_quad(const void* x, const void* w, int64_t M, int64_t N, int64_t K, void* out, float* stamps,
                                    int dbg, int grid_limit, hipStream_t stream) {
     if (!x || !w || !out || M <= 0 || N % 256 || K % 64 || K < 128) { va_set_error("va_dbg_gemm_nt_quad: bad arguments"); return VA_ERR_INVALID; }
-    if (dbg == 5 && !stamps) { va_set_error("va_dbg_gemm_nt_quad: dbg 5 needs a stamp buffer"); return VA_ERR_INVALID; }
+    if ((dbg == 5 || dbg >= 8) && !stamps) { va_set_error("va_dbg_gemm_nt_quad: dbg 5 needs a stamp buffer"); return VA_ERR_INVALID; }
     EpiArgs ep{out, stamps, nullptr, nullptr, nullptr, (int)N, 0u, 0u, 1.f};
     const bf16_t* X = (const bf16_t*)x;
     const bf16_t* W = (const bf16_t*)w;
@@ -41,6 +44,15 @@ extern "C" int va_dbg_gemm_nt_quad(const void* x, const void* w, int64_t M, int6
         case 5: return launch_quad<VA_EPI_BF16, false, 5>(X, W, m, n, k, k, k, ep, stream, grid_limit);
         case 6: return launch_quad<VA_EPI_BF16, false, 6>(X, W, m, n, k, k, k, ep, stream, grid_limit);
         case 7: return launch_quad<VA_EPI_BF16, false, 7>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 8: return launch_quad<VA_EPI_BF16, false, 8>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 9: return launch_quad<VA_EPI_BF16, false, 9>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 10: return launch_quad<VA_EPI_BF16, false, 10>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 11: return launch_quad<VA_EPI_BF16, false, 11>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 12: return launch_quad<VA_EPI_BF16, false, 12>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 13: return launch_quad<VA_EPI_BF16, false, 13>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 14: return launch_quad<VA_EPI_BF16, false, 14>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 15: return launch_quad<VA_EPI_BF16, false, 15>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 16: return launch_quad<VA_EPI_BF16, false, 16>(X, W, m, n, k, k, k, ep, stream, grid_limit);
     }
     va_set_error("va_dbg_gemm_nt_quad: unknown variant %d", dbg);
     return VA_ERR_INVALID;

@@ -8,20 +8,21 @@
 //   * operand tiles are staged with 16-byte direct-to-LDS loads (global_load_lds_dwordx4).  The LDS image
 //     is lane-linear; bank conflicts of the ds_read_b128 fragment reads are removed by permuting the
 //     per-lane SOURCE address (XOR on the 16-byte chunk index) and applying the same XOR when reading.
-//   * each wave owns a (BM/WM) x (BN/WN) sub-tile as 16x16x32 bf16 MFMAs.  The weight tile is the MFMA
-//     A operand and the activation tile the B operand, so an accumulator lane holds 4 consecutive
-//     output columns of one output row.
+//   * each wave owns a (BM/WM) x (BN/WN) sub-tile as 16x16x32 bf16 MFMAs.  In the 128-wide "pair" kernel the
+//     weight tile is the MFMA A operand, so an accumulator lane holds 4 consecutive output columns of one
+//     output row; the 256-wide kernels put the activation there and stage the weight rows in a permuted order,
+//     so that neighbouring lanes hold neighbouring columns of the same output row (see wide_wrow).
 //   * launch-order block ids are remapped so that the blocks sharing an XCD walk neighbouring tiles.
 //
 // Three main loops:
 //   quad  (256x256 tile, 4 waves of 128x128, persistent): the default for large problems; see the kernel.
-//   ring  (256x256 tile, 8 waves): K advances in 32-wide stages through a 5-slot LDS ring (5 x 32 KiB, the
+//   ring  (256x256 tile, 8 waves of 64 x 128): K advances in 32-wide stages through a 5-slot LDS ring (5 x 32 KiB, the
 //         whole LDS of a CU).  Default form ("paired"): loads are issued for two stages at a time so that
 //         both 64-byte halves of every 128-byte line are requested back to back, one pair in flight while
 //         two stages compute, counted s_waitcnt + raw s_barrier every two stages.  Alternative form: one
 //         stage per barrier, three stages in flight.  MFMA fragments are read from LDS one stage ahead of
 //         their use, interleaved with the MFMAs of the current stage, so the LDS pipe and the matrix pipe
-//         overlap.  The epilogue writes 64 contiguous bytes per output row and store instruction.
+//         overlap.  An epilogue store instruction writes 4 rows x 128 (2-byte outputs) or 256 contiguous bytes.
 //   pair  (128x128 tile, 4 waves; also selectable at 256x256): K advances in 64-wide tiles through two
 //         buffers, next tile issued before the current tile's MFMAs, vmcnt(0) + barrier per tile.  Used
 //         for small M and short K.
@@ -113,132 +114,200 @@ VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M
     }
 }
 
-// Which weight row (= output column, relative to the wave's 64-column block base `row & ~63`) LDS row `row`
-// of the W image holds in the 256-wide kernels.  MFMA row r of 16-row block a lands in lane group r>>2,
-// register r&3; the order is chosen so that ONE store instruction of the epilogue covers 64 contiguous
-// bytes of every output row (whole 32-byte sectors): for 2-byte outputs lane group g must own columns
-// 8g..8g+7 of each 32-column half, for 4-byte outputs the natural order already does that.
-template <int EPI>
+// The 256-wide kernels issue their MFMAs with the ACTIVATION fragment as the A operand and the weight fragment as B, so
+// an accumulator register j of lane l belongs to output row 4*(l>>4) + j of its 16-row block and to the weight row that
+// lane l & 15 of the B fragment carried.  A lane therefore owns, for each of its rows, one value per 16-row weight block
+// of the wave (NV = WCOLS / 16 of them).  Which weight row LDS row `row` of the W image holds is chosen so that those NV
+// values are CONSECUTIVE output columns and neighbouring lanes continue them:
+//   2-byte outputs: lane r owns columns r*NV .. r*NV + NV-1 of the wave's WCOLS columns -- one 16-byte (NV = 8) or
+//                   8-byte (NV = 4) store per lane and row, 16 lanes = 256 (128) contiguous bytes, 4 rows per instruction;
+//   4-byte outputs (f32 + bias + residual) keep the weight as the A operand and the natural row order: register j of
+//                   lane l is row l & 15, column 16*v + 4*(l>>4) + j.  That epilogue reads and writes 4 bytes per element
+//                   and is bound by those bytes, not by store issue; the row-contiguous form measured 6 % slower on the
+//                   K = 1024 shape and equal at K = 4096.
+// What this buys: a store instruction whose CONSECUTIVE lanes write consecutive addresses.  Measured on the four-wave
+// kernel (timing-only builds that store zeros, tools/quad_epi_prof.py): 32 stores of 16 rows x 64 bytes, the 64 bytes of a
+// row spread over lanes 16 apart (the accumulator layout with the weight as the A operand), hold the wave for 8400
+// cycles per tile; 8 rows x 128 bytes or 4 rows x 256 bytes from neighbouring lanes for 3400-3500.
+template <int EPI, int WCOLS>
 VA_DEVINL int wide_wrow(int row) {
-    const int r = row & 15, a = (row >> 4) & 3;
+    constexpr int NV = WCOLS / 16;
+    const int r = row & 15, v = (row >> 4) % NV, base = row - (row % WCOLS);
     if (EPI == VA_EPI_F32) return row;
-    return (row & ~63) + (a >> 1) * 32 + (r >> 2) * 8 + (a & 1) * 4 + (r & 3);
+    return base + r * NV + v;
+}
+// Whether the weight fragment is the MFMA's A operand (the 4-byte epilogue) or its B operand (the 2-byte ones).
+template <int EPI>
+constexpr bool w_is_a() { return EPI == VA_EPI_F32; }
+
+template <int N>
+struct PackedBf16;
+template <>
+struct PackedBf16<8> { typedef u32x4_t type; };
+template <>
+struct PackedBf16<4> { typedef u32x2_t type; };
+
+template <int NV>
+VA_DEVINL typename PackedBf16<NV>::type pack_run(const float* v) {
+    typename PackedBf16<NV>::type p;
+#pragma unroll
+    for (int q = 0; q < NV / 2; ++q) p[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+    return p;
+}
+template <int NV>
+VA_DEVINL void unpack_run(typename PackedBf16<NV>::type p, float* v) {
+#pragma unroll
+    for (int q = 0; q < NV / 2; ++q) {
+        v[2 * q] = __uint_as_float(p[q] << 16);
+        v[2 * q + 1] = __uint_as_float(p[q] & 0xffff0000u);
+    }
 }
 
-// Epilogue for the column-permuted layout of the 256-wide kernels (weight rows staged per wide_wrow): each
-// 16-byte store of a lane group sits next to its neighbours', so a store instruction writes 64 contiguous
-// bytes per output row.
-// FULL_M: all of the wave's rows exist, so the row loop carries no branches (a skipped row block would make
-// the compiler drain the memory counter in front of every later block's stores).
-// HAS_BIAS = false: the caller knows there is no bias and the adds are left out (with a run-time test inside, the add
-// would become an add plus a select on every accumulator value); true: a null bias pointer adds zeros.
-// RESID_AHEAD (f32 epilogue, all rows present): the wave's whole residual block is requested before the first row
-// block is processed, instead of four loads in front of each row block's stores (the compiler may not move loads
-// of `resid` above stores to `out` on its own).  Safe for out == resid: a lane reads exactly the elements it later
-// writes.  Costs 4*TM*4 registers: for the kernel whose accumulators live in the accumulation registers.
+// Epilogue of the 256-wide kernels for the layout above.  get(v, b, j): accumulator register j of 16-row block b and
+// weight block v.  Stores carry the non-temporal hint: the output is read by a later kernel and is hundreds of times the
+// size of an L2, where it would only evict the operand panels that neighbouring tiles are about to re-read (the main loop
+// of the four-wave kernel runs 9 % faster behind such an epilogue).
+// FULL_M: all of the wave's rows exist, so the row loop carries no branches (a skipped row would make the compiler drain
+// the memory counter in front of every later row's stores).
+// HAS_BIAS = false: the caller knows there is no bias and the adds are left out; true: a null bias pointer adds zeros.
+// RESID_AHEAD: unused (kept so that call sites read the same); the f32 epilogue always requests one row block ahead.
 // CAN_DROP = false compiles the fused-dropout branches out (the four-wave kernel has no registers to spare for them).
-template <int EPI, int TM, bool FULL_M = false, bool HAS_BIAS = true, bool RESID_AHEAD = false, bool CAN_DROP = true>
-VA_DEVINL void store_tile_wide(const f32x4_t (&acc)[4][TM], const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
+#ifndef VA_NT_16
+#define VA_NT_16 1
+#endif
+template <typename V>
+VA_DEVINL void put_16(V v, V* p) {
+    if (VA_NT_16) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// Two 16-byte pieces per lane -- `lo` at p (row lane & 15 of a 16-row block, 64 contiguous bytes per row over the four
+// lane groups) and `hi` 64 bytes further along the same row -- written as whole 128-byte lines: the upper half of each
+// 16-lane row hands its `hi` to the lower half's rows and vice versa (one rotate-by-8 per register, merged by the DPP
+// bank mask), so that one store instruction covers 8 rows x 128 bytes instead of 16 rows x 64.  All 16 rows must exist.
+template <typename V>
+VA_DEVINL void store_line_pairs(char* p, V lo, V hi, int64_t row_bytes, bool upper) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    const i32x4_t l = __builtin_bit_cast(i32x4_t, lo), h = __builtin_bit_cast(i32x4_t, hi);
+    i32x4_t a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = __builtin_amdgcn_update_dpp(l[j], h[j], 0x128, 0xf, 0xc, false);   // row_ror:8 into lanes 8..15 of each row
+        b[j] = __builtin_amdgcn_update_dpp(l[j], h[j], 0x128, 0xf, 0x3, false);   // ... into lanes 0..7
+    }
+    char* pa = upper ? p + 64 - 8 * row_bytes : p;      // rows 0..7 of the block, both halves of their lines
+    char* pb = upper ? p : p + 64 + 8 * row_bytes;      // rows 8..15
+    __builtin_nontemporal_store(a, (i32x4_t*)pa);
+    __builtin_nontemporal_store(b, (i32x4_t*)pb);
+}
+
+template <int EPI, int TM, int NV, bool FULL_M, bool HAS_BIAS, bool RESID_AHEAD, bool CAN_DROP, typename Get>
+VA_DEVINL void store_tile_rows(Get get, const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
     const int ldc = ep.ldc;
-    const int g = lane >> 4;
-    // v[4a+j] = acc[a][b][j] is output column  col(a) + j  (see wide_wrow)
-    auto col = [&](int a) { return EPI == VA_EPI_F32 ? n_wave + a * 16 + 4 * g : n_wave + (a >> 1) * 32 + g * 8 + (a & 1) * 4; };
-    float bias[16];
+    const int r = lane & 15, g = lane >> 4;
+    typedef typename PackedBf16<NV>::type pk_t;
+    if (EPI == VA_EPI_F32) {
+        // weight as the A operand: register q of (v, b) is row b*16 + r, column 16*v + 4*g + q.  The residual values of
+        // the NEXT row block are requested before this block's stores, so that waiting for them does not wait for the
+        // stores (memory operations retire in issue order; the compiler may not move loads of `resid` above stores to
+        // `out` on its own).  Safe for out == resid: a lane reads exactly the elements it later writes.
 #pragma unroll
-    for (int j = 0; j < 16; ++j) bias[j] = 0.f;
-    if (HAS_BIAS && EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
+        for (int h = 0; h < NV / 4; ++h) {
+            auto col = [&](int a) { return n_wave + (4 * h + a) * 16 + 4 * g; };
+            f32x4_t bias[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) *(f32x4_t*)(bias + 4 * a) = *(const f32x4_t*)(ep.bias + col(a));
-    }
-    constexpr bool AHEAD = RESID_AHEAD && FULL_M && EPI == VA_EPI_F32;
-    f32x4_t ahead[AHEAD ? TM : 1][4];
-    if (AHEAD && ep.resid != nullptr) {
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-                ahead[AHEAD ? b : 0][a] = *(const f32x4_t*)(ep.resid + (size_t)(m_wave + b * 16 + (lane & 15)) * ldc + col(a));
-    }
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int m = m_wave + b * 16 + (lane & 15);
-        if (!FULL_M && m >= M) continue;
-        const size_t o_lo = (size_t)m * ldc + col(0), o_hi = (size_t)m * ldc + col(2);   // 2-byte outputs: 8 + 8 columns
-        float v[16];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * a + j] = HAS_BIAS ? acc[a][b][j] + bias[4 * a + j] : acc[a][b][j];
-        if (EPI == VA_EPI_BF16) {
-            u32x4_t lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-            u32x4_t hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
-            *(u32x4_t*)((bf16_t*)ep.out + o_lo) = lo;
-            *(u32x4_t*)((bf16_t*)ep.out + o_hi) = hi;
-        } else if (EPI == VA_EPI_BIAS_GELU) {
-            u32x4_t lo = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-            u32x4_t hi = {pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
-            *(u32x4_t*)((bf16_t*)ep.out + o_lo) = lo;
-            *(u32x4_t*)((bf16_t*)ep.out + o_hi) = hi;
-            float gl[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) gl[j] = gelu_erf(v[j]);
-            if (CAN_DROP && ep.drop_thi) {
-                drop_run<8>(gl, (uint32_t)o_lo, ep);
-                drop_run<8>(gl + 8, (uint32_t)o_hi, ep);
+            for (int a = 0; a < 4; ++a) {
+                bias[a] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (HAS_BIAS && ep.bias != nullptr) bias[a] = *(const f32x4_t*)(ep.bias + col(a));
             }
-            u32x4_t glo = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3]), pack_bf16x2(gl[4], gl[5]), pack_bf16x2(gl[6], gl[7])};
-            u32x4_t ghi = {pack_bf16x2(gl[8], gl[9]), pack_bf16x2(gl[10], gl[11]), pack_bf16x2(gl[12], gl[13]), pack_bf16x2(gl[14], gl[15])};
-            *(u32x4_t*)((bf16_t*)ep.out2 + o_lo) = glo;
-            *(u32x4_t*)((bf16_t*)ep.out2 + o_hi) = ghi;
-        } else if (EPI == VA_EPI_GELU_ONLY) {
-            float gl[16];
+            f32x4_t nxt[4];
+            auto fetch = [&](int b) {
+                const int m = m_wave + b * 16 + r;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) gl[j] = gelu_erf(v[j]);
-            if (CAN_DROP && ep.drop_thi) {
-                drop_run<8>(gl, (uint32_t)o_lo, ep);
-                drop_run<8>(gl + 8, (uint32_t)o_hi, ep);
-            }
-            u32x4_t glo = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3]), pack_bf16x2(gl[4], gl[5]), pack_bf16x2(gl[6], gl[7])};
-            u32x4_t ghi = {pack_bf16x2(gl[8], gl[9]), pack_bf16x2(gl[10], gl[11]), pack_bf16x2(gl[12], gl[13]), pack_bf16x2(gl[14], gl[15])};
-            *(u32x4_t*)((bf16_t*)ep.out + o_lo) = glo;
-            *(u32x4_t*)((bf16_t*)ep.out + o_hi) = ghi;
-        } else if (EPI == VA_EPI_F32) {
-            if (CAN_DROP && ep.drop_thi) {
+                for (int a = 0; a < 4; ++a)
+                    nxt[a] = (ep.resid != nullptr && (FULL_M || m < M)) ? *(const f32x4_t*)(ep.resid + (size_t)m * ldc + col(a))
+                                                                       : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            };
+            fetch(0);
 #pragma unroll
-                for (int a = 0; a < 4; ++a) drop_run<4>(v + 4 * a, (uint32_t)((size_t)m * ldc + col(a)), ep);
-            }
-            if (ep.resid != nullptr) {
+            for (int b = 0; b < TM; ++b) {
+                const int m = m_wave + b * 16 + r;
+                f32x4_t cur[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const f32x4_t rv = AHEAD ? ahead[AHEAD ? b : 0][a] : *(const f32x4_t*)(ep.resid + (size_t)m * ldc + col(a));
+                for (int a = 0; a < 4; ++a) cur[a] = nxt[a];
+                if (b + 1 < TM) fetch(b + 1);
+                if (!FULL_M && m >= M) continue;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[4 * a + j] += rv[j];
+                for (int a2 = 0; a2 < 4; a2 += 2) {
+                    f32x4_t res[2];
+#pragma unroll
+                    for (int a = a2; a < a2 + 2; ++a) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = HAS_BIAS ? get(4 * h + a, b, q) + bias[a][q] : get(4 * h + a, b, q);
+                        if (CAN_DROP && ep.drop_thi) drop_run<4>(v, (uint32_t)((size_t)m * ldc + col(a)), ep);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += cur[a][q];
+                        res[a - a2] = (f32x4_t){v[0], v[1], v[2], v[3]};
+                    }
+                    float* o = (float*)ep.out + (size_t)m * ldc + col(a2);
+                    if (FULL_M) {      // blocks a2, a2 + 1 are the two halves of a 128-byte line: whole lines, non-temporal
+                        store_line_pairs((char*)o, res[0], res[1], (int64_t)ldc * 4, (lane & 8) != 0);
+                    } else {
+                        *(f32x4_t*)o = res[0];
+                        *(f32x4_t*)(o + 16) = res[1];
+                    }
                 }
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-                *(f32x4_t*)((float*)ep.out + (size_t)m * ldc + col(a)) = (f32x4_t){v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3]};
-        } else {  // VA_EPI_GELU_BWD
-            const u32x4_t p_lo = *(const u32x4_t*)(ep.aux + o_lo);
-            const u32x4_t p_hi = *(const u32x4_t*)(ep.aux + o_hi);
-            float r[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r[2 * j] = v[2 * j] * gelu_erf_grad(__uint_as_float(p_lo[j] << 16));
-                r[2 * j + 1] = v[2 * j + 1] * gelu_erf_grad(__uint_as_float(p_lo[j] & 0xffff0000u));
-                r[8 + 2 * j] = v[8 + 2 * j] * gelu_erf_grad(__uint_as_float(p_hi[j] << 16));
-                r[9 + 2 * j] = v[9 + 2 * j] * gelu_erf_grad(__uint_as_float(p_hi[j] & 0xffff0000u));
-            }
-            if (CAN_DROP && ep.drop_thi) {
-                drop_run<8>(r, (uint32_t)o_lo, ep);
-                drop_run<8>(r + 8, (uint32_t)o_hi, ep);
-            }
-            u32x4_t lo = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
-            u32x4_t hi = {pack_bf16x2(r[8], r[9]), pack_bf16x2(r[10], r[11]), pack_bf16x2(r[12], r[13]), pack_bf16x2(r[14], r[15])};
-            *(u32x4_t*)((bf16_t*)ep.out + o_lo) = lo;
-            *(u32x4_t*)((bf16_t*)ep.out + o_hi) = hi;
         }
+        return;
     }
+    const int col = n_wave + r * NV;
+    float bias[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) bias[q] = 0.f;
+    if (HAS_BIAS && EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
+#pragma unroll
+        for (int q = 0; q < NV; q += 4) *(f32x4_t*)(bias + q) = *(const f32x4_t*)(ep.bias + col + q);
+    }
+    // x GELU': the saved pre-activation of the NEXT row is requested before this row's store, so that waiting for it
+    // does not wait for the store (memory operations retire in issue order)
+    pk_t aux_next = {};
+    auto aux_row = [&](int i) {      // i = 4 * b + j
+        const int m = m_wave + (i >> 2) * 16 + 4 * g + (i & 3);
+        return (FULL_M || m < M) ? *(const pk_t*)(ep.aux + (size_t)m * ldc + col) : pk_t{};
+    };
+    if (EPI == VA_EPI_GELU_BWD) aux_next = aux_row(0);
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m_wave + b * 16 + 4 * g + j;
+            pk_t aux_cur = aux_next;
+            if (EPI == VA_EPI_GELU_BWD && 4 * b + j + 1 < 4 * TM) aux_next = aux_row(4 * b + j + 1);
+            if (!FULL_M && m >= M) continue;
+            const size_t o = (size_t)m * ldc + col;
+            float v[NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] = HAS_BIAS ? get(q, b, j) + bias[q] : get(q, b, j);
+            if (EPI == VA_EPI_BF16) {
+                put_16(pack_run<NV>(v), (pk_t*)((bf16_t*)ep.out + o));
+            } else if (EPI == VA_EPI_BIAS_GELU || EPI == VA_EPI_GELU_ONLY) {
+                if (EPI == VA_EPI_BIAS_GELU) put_16(pack_run<NV>(v), (pk_t*)((bf16_t*)ep.out + o));
+                float gl[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) gl[q] = gelu_erf(v[q]);
+                if (CAN_DROP && ep.drop_thi) drop_run<NV>(gl, (uint32_t)o, ep);
+                put_16(pack_run<NV>(gl), (pk_t*)((bf16_t*)(EPI == VA_EPI_BIAS_GELU ? ep.out2 : ep.out) + o));
+            } else {  // VA_EPI_GELU_BWD
+                float pre[NV], rr[NV];
+                unpack_run<NV>(aux_cur, pre);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) rr[q] = v[q] * gelu_erf_grad(pre[q]);
+                if (CAN_DROP && ep.drop_thi) drop_run<NV>(rr, (uint32_t)o, ep);
+                put_16(pack_run<NV>(rr), (pk_t*)((bf16_t*)ep.out + o));
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,15 +414,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pair_kernel(const bf16_t*
 }
 
 // ------------------------------------------------------------------------------------------------
-// "ring" loop: 256 x 256 tile, 8 waves (2 x 4), BK = 32 stages in a 5-slot ring (all 160 KiB of LDS).
+// "ring" loop: 256 x 256 tile, 8 waves (4 x 2, 64 x 128 each), BK = 32 stages in a 5-slot ring (all 160 KiB of LDS).
 // Rows are 64 B (4 chunks); chunk XOR (3 * ((row>>3)&1)) makes the 16x16x32 fragment reads conflict-free.
-// Weight rows are staged in a permuted order (wide_wrow) so that the epilogue stores whole sectors.
+// Weight rows are staged in a permuted order (wide_wrow) so that the epilogue's lanes store contiguous row pieces.
 // ------------------------------------------------------------------------------------------------
 template <int EPI, bool PAIRED>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                            int M, int N, int K, int ldx, int ldw, EpiArgs ep) {
-    constexpr int BM = 256, BN = 256, BK = 32, WN = 4, NT = 512;
-    constexpr int TM = 8, TN = 4;                 // per wave: 128 (m) x 64 (n)
+    constexpr int BM = 256, BN = 256, BK = 32, WN = 2, NT = 512;
+    constexpr int TM = 4, TN = 8;                 // per wave: 64 (m) x 128 (n): a lane of the epilogue owns 8 consecutive columns
     constexpr int OP_BYTES = 256 * BK * 2;        // 16 KiB per operand per stage
     constexpr int STAGE_BYTES = 2 * OP_BYTES;     // 32 KiB
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -378,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
         int grow = m0 + row;
         grow = grow < M ? grow : M - 1;
         xsrc[i] = X + (size_t)grow * ldx + c * 8;
-        wsrc[i] = W + (size_t)(n0 + wide_wrow<EPI>(row)) * ldw + c * 8;
+        wsrc[i] = W + (size_t)(n0 + wide_wrow<EPI, 128>(row)) * ldw + c * 8;
     }
     auto stage = [&](int kt, int slot) {
         char* xb = smem + slot * STAGE_BYTES;
@@ -399,15 +468,15 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
     // fragment offset of this lane inside a 16-row block: row (lane&15), chunk (lane>>4) swizzled
     const int frow = lane & 15;
     const int foff = frow * 64 + (((lane >> 4) ^ (((frow >> 3) & 1) * 3)) << 4);
-    const int woff = wn * 64 * 64 + foff;     // wave's first W row * 64 B
-    const int xoff = wm * 128 * 64 + foff;
+    const int woff = wn * 128 * 64 + foff;    // wave's first W row * 64 B
+    const int xoff = wm * 64 * 64 + foff;
 
     // Fragments live in registers one stage ahead of the MFMAs that consume them: while stage kt's 32 MFMAs
     // issue, stage kt+1's fragments are read from LDS into the registers the retired ones leave behind
-    // (the X fragment of row block b right after its 4 MFMAs; the W fragments into the other half of a
+    // (the W fragment of column block a right after its 4 MFMAs; the X fragments into the other half of a
     // double buffer).  Matrix pipe and LDS pipe therefore overlap instead of alternating.
-    bf16x8_t wf[2][TN];
-    bf16x8_t xf[TM];
+    bf16x8_t wf[TN];
+    bf16x8_t xf[2][TM];
     auto frag_w = [&](int slot, int a) {
         return *(const bf16x8_t*)(smem + slot * STAGE_BYTES + OP_BYTES + woff + a * 16 * 64);
     };
@@ -419,12 +488,13 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
         constexpr int P = decltype(parity)::value;
         constexpr bool PREFETCH = decltype(prefetch)::value;
 #pragma unroll
-        for (int b = 0; b < TM; ++b) {
+        for (int a = 0; a < TN; ++a) {
 #pragma unroll
-            for (int a = 0; a < TN; ++a) acc[a][b] = mfma16(wf[P][a], xf[b], acc[a][b]);
+            for (int b = 0; b < TM; ++b)
+                acc[a][b] = w_is_a<EPI>() ? mfma16(wf[a], xf[P][b], acc[a][b]) : mfma16(xf[P][b], wf[a], acc[a][b]);
             if (PREFETCH) {
-                xf[b] = frag_x(next_slot, b);
-                if (b < TN) wf[P ^ 1][b] = frag_w(next_slot, b);
+                wf[a] = frag_w(next_slot, a);
+                if (a < TM) xf[P ^ 1][a] = frag_x(next_slot, a);
             }
         }
         if (PREFETCH) {
@@ -471,9 +541,9 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
+        for (int a = 0; a < TN; ++a) wf[a] = frag_w(0, a);
 #pragma unroll
-        for (int b = 0; b < TM; ++b) xf[b] = frag_x(0, b);
+        for (int b = 0; b < TM; ++b) xf[0][b] = frag_x(0, b);
         body(P0{}, Yes{}, 1);                                 // stage 0
         int slot = 1;                                         // slot of stage j
         for (int j = 1; j + 2 < nk; j += 2) {
@@ -496,9 +566,9 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
         __builtin_amdgcn_s_barrier();                          // ... and everybody else's
         asm volatile("" ::: "memory");
     #pragma unroll
-        for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
+        for (int a = 0; a < TN; ++a) wf[a] = frag_w(0, a);
     #pragma unroll
-        for (int b = 0; b < TM; ++b) xf[b] = frag_x(0, b);
+        for (int b = 0; b < TM; ++b) xf[0][b] = frag_x(0, b);
 
         // At the top of stage kt the loads of stages kt+1..kt+3 are outstanding; vmcnt(8) retires kt+1 (needed
         // by this stage's prefetch reads) and leaves two stages in flight across the barrier.  The barrier also
@@ -537,8 +607,11 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(const bf16_t* __restr
         body(P1{}, No{}, 0);
     }
 
-    if (m0 + wm * 128 + 128 <= M) store_tile_wide<EPI, TM, true>(acc, ep, M, m0 + wm * 128, n0 + wn * 64, lane);
-    else store_tile_wide<EPI, TM, false>(acc, ep, M, m0 + wm * 128, n0 + wn * 64, lane);
+    auto get = [&](int v, int b, int j) { return acc[v][b][j]; };
+    if (m0 + wm * 64 + 64 <= M)
+        store_tile_rows<EPI, TM, TN, true, true, false, true>(get, ep, M, m0 + wm * 64, n0 + wn * 128, lane);
+    else
+        store_tile_rows<EPI, TM, TN, false, true, false, true>(get, ep, M, m0 + wm * 64, n0 + wn * 128, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -567,7 +640,10 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     constexpr int RING = 5, LPS = 8;              // loads per thread and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const uint64_t t_entry = DBG == 5 ? __builtin_amdgcn_s_memtime() : 0;
+    // diagnostic instantiations: 5 stamps only; 8 stamps + epilogue without its stores; 9 stamps + tiles assigned
+    // statically (no ticket atomics); 10 stamps + epilogue that stores without reading the accumulators
+    constexpr bool STAMP = DBG == 5 || (DBG >= 8 && DBG <= 16);
+    const uint64_t t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -600,7 +676,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i) {
         const int q = i * NT + tid, row = q >> 2, c = (q & 3) ^ (((row >> 3) & 1) * 3);
         xvo[i] = (row * ldx + c * 8) * 2;
-        wvo[i] = (wide_wrow<EPI>(row) * ldw + c * 8) * 2;
+        wvo[i] = (wide_wrow<EPI, 128>(row) * ldw + c * 8) * 2;
     }
     // load i (0..7) of stage kt of tile t into ring slot `slot`: X chunks first, then W chunks
     auto load_one = [&](const Tile& t, int kt, int slot, int i) {
@@ -627,11 +703,15 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     // between the two register files inside the loop.  Volatile asm statements keep their order, and the empty
     // memory-clobbering statements pin the loads between them, so the instruction stream is the written one:
     // per 16-row block  4 MFMAs | W fragment read | 4 MFMAs | X fragment read + one global load.
-    auto mf = [](f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    // (w, x) in; for the 2-byte epilogues issued as A = x, B = w: a lane's registers are then four output ROWS of one
+    // weight row (see wide_wrow)
+    auto mf = [](f32x4_t& c, const bf16x8_t& w, const bf16x8_t& x) {
+        if (w_is_a<EPI>()) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %1, %0" : "+a"(c) : "v"(w), "v"(x));
     };
-    auto mf_first = [](f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {   // first stage of a tile: C = A*B + 0
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    auto mf_first = [](f32x4_t& c, const bf16x8_t& w, const bf16x8_t& x) {   // first stage of a tile: C = A*B + 0
+        if (w_is_a<EPI>()) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(x));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %1, 0" : "=a"(c) : "v"(w), "v"(x));
     };
 #define VA_PIN asm volatile("" ::: "memory")
     // One stage: 64 MFMAs; the next stage's fragments are read into the registers just retired and the eight
@@ -726,6 +806,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     __builtin_amdgcn_s_barrier();                          // ... and everybody else's
     asm volatile("" ::: "memory");
     int vn = collect(RING - 1);                            // the tile after this one (>= tiles: none)
+    if (DBG == 9) vn = (int)blockIdx.x + (int)gridDim.x;
 #pragma unroll
     for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(0, a);
 #pragma unroll
@@ -735,7 +816,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     // next one (read by this stage's prefetch) and the barrier tells that every wave has taken the current stage
     // into registers and is done with the previous one, whose slot the stage four ahead refills during this body.
     int slot = 0;                                          // ring slot of the current stage
-    uint64_t t_sync = 0, t_body = 0, t_epi = 0, t_last = 0, t_first = 0, w_first = 0;   // DBG 5: cycles in waits+barriers / in stage bodies
+    uint64_t t_sync = 0, t_body = 0, t_epi = 0, t_bound = 0, t_last = 0, t_first = 0, w_first = 0;   // stamped builds: cycles in waits+barriers / stage bodies / epilogues / tile hand-over
     // `relaxed`: the first three stages after the epilogue of a tile whose rows all exist.  Memory operations
     // retire in issue order and the loads of this tile's stages 1..3 went out before the epilogue's stores, so the
     // loads a stage needs are followed by two stages' loads AND those stores (32 instructions per wave for one
@@ -744,22 +825,23 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     constexpr int STORES = (EPI == VA_EPI_BF16 || EPI == VA_EPI_GELU_BWD || EPI == VA_EPI_GELU_ONLY) ? 32 : 64;
     constexpr int RELAXED = 2 * LPS + STORES < 63 ? 2 * LPS + STORES : 63;
     auto sync = [&](bool relaxed) {
-        if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_body += now - t_last; t_last = now; }
+        if (STAMP) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_body += now - t_last; t_last = now; }
         if (relaxed) wait_vm<RELAXED>();
         else wait_vm<2 * LPS>();
         if (DBG != 3) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_sync += now - t_last; t_last = now; }
+        if (STAMP) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_sync += now - t_last; t_last = now; }
     };
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
-    if (DBG == 5) { t_last = t_first = __builtin_amdgcn_s_memtime(); w_first = __builtin_amdgcn_s_memrealtime(); }
+    if (STAMP) { t_last = t_first = __builtin_amdgcn_s_memtime(); w_first = __builtin_amdgcn_s_memrealtime(); }
     bool after_epilogue = false;
     for (;;) {
         // the tile whose first four stages ride in this tile's last four bodies; after the last tile the same
         // loads are issued once more (valid addresses, never read) so that the counted waits stay uniform
         Tile nxt;
         set_tile(vn < tiles ? vn : v, nxt);
+        if (STAMP) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_bound += now - t_last; t_last = now; }
         // stage kt issues the loads of stage kt+4: of this tile, or of the next one from its stage 0 on
         auto stage_one = [&](auto parity, auto first, int kt, bool relaxed) {
             const bool in_cur = kt + 4 < nk;
@@ -778,21 +860,73 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 
         // the asm MFMAs are opaque to the compiler's hazard tracking: let the last results retire before they are read
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_body += now - t_last; t_last = now; }
+        if (STAMP) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_body += now - t_last; t_last = now; }
         const bool more = vn < tiles;
-        const int ticket = more ? draw() : 0;
+        const int ticket = (more && DBG != 9) ? draw() : 0;
         const bool full = cur.m0 + wm * 128 + 128 <= M;
+        if (DBG >= 11 && DBG <= 16) {
+            // timing only: the same 32 KiB per wave stored from zeroed registers in other shapes -- 11: 8 rows x 128 B per
+            // instruction, 12: 4 rows x 256 B, 13: as 10 with the non-temporal hint, 14: as 12 with it, 15: 16 rows x 64 B
+            // but the two halves of a line 16 instructions apart, 16: 8-byte stores (16 rows x 32 B, 64 instructions)
+            u32x4_t z = {0u, 0u, 0u, 0u};
+            asm volatile("" : "+v"(z));
+            bf16_t* base = (bf16_t*)ep.out + (size_t)(cur.m0 + wm * 128) * ep.ldc + cur.n0 + wn * 128;
+            if (cur.m0 + wm * 128 + 128 <= M) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            if (full) store_tile_wide<EPI, TM, true, HAS_BIAS, true, false>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
-            else store_tile_wide<EPI, TM, false, HAS_BIAS, false, false>(acc[hh], ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128 + hh * 64, lane);
+                for (int i = 0; i < 32; ++i) {
+                    if (DBG == 11) *(u32x4_t*)(base + (size_t)((i >> 1) * 8 + (lane >> 3)) * ep.ldc + (i & 1) * 64 + (lane & 7) * 8) = z;
+                    if (DBG == 12) *(u32x4_t*)(base + (size_t)(i * 4 + (lane >> 4)) * ep.ldc + (lane & 15) * 8) = z;
+                    if (DBG == 13) __builtin_nontemporal_store(z, (u32x4_t*)(base + (size_t)((i >> 2) * 16 + (lane & 15)) * ep.ldc + (i & 3) * 32 + (lane >> 4) * 8));
+                    if (DBG == 14) __builtin_nontemporal_store(z, (u32x4_t*)(base + (size_t)(i * 4 + (lane >> 4)) * ep.ldc + (lane & 15) * 8));
+                    if (DBG == 15) *(u32x4_t*)(base + (size_t)((i & 7) * 16 + (lane & 15)) * ep.ldc + (i >> 3) * 32 + (lane >> 4) * 8) = z;
+                    if (DBG == 16) {
+                        *(u32x2_t*)(base + (size_t)((i >> 2) * 16 + (lane & 15)) * ep.ldc + (i & 3) * 32 + (lane >> 4) * 4) = (u32x2_t){z[0], z[1]};
+                        *(u32x2_t*)(base + (size_t)((i >> 2) * 16 + (lane & 15)) * ep.ldc + (i & 3) * 32 + 16 + (lane >> 4) * 4) = (u32x2_t){z[2], z[3]};
+                    }
+                }
+            }
+        } else if (DBG == 8 || DBG == 10) {
+            // timing only: the 2-byte epilogue's two halves apart -- 8 reads and converts every accumulator and drops the
+            // result, 10 issues the 32 stores of a full tile from registers that hold zeros
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    u32x4_t lo = {0u, 0u, 0u, 0u}, hi = {0u, 0u, 0u, 0u};
+                    if (DBG == 8) {
+                        lo = (u32x4_t){pack_bf16x2(acc[hh][0][b][0], acc[hh][0][b][1]), pack_bf16x2(acc[hh][0][b][2], acc[hh][0][b][3]),
+                                       pack_bf16x2(acc[hh][1][b][0], acc[hh][1][b][1]), pack_bf16x2(acc[hh][1][b][2], acc[hh][1][b][3])};
+                        hi = (u32x4_t){pack_bf16x2(acc[hh][2][b][0], acc[hh][2][b][1]), pack_bf16x2(acc[hh][2][b][2], acc[hh][2][b][3]),
+                                       pack_bf16x2(acc[hh][3][b][0], acc[hh][3][b][1]), pack_bf16x2(acc[hh][3][b][2], acc[hh][3][b][3])};
+                        asm volatile("" ::"v"(lo), "v"(hi));
+                    } else {
+                        asm volatile("" : "+v"(lo), "+v"(hi));
+                        const int m = cur.m0 + wm * 128 + b * 16 + (lane & 15);
+                        if (m < M) {
+                            bf16_t* o = (bf16_t*)ep.out + (size_t)m * ep.ldc + cur.n0 + wn * 128 + hh * 64 + (lane >> 4) * 8;
+                            *(u32x4_t*)o = lo;
+                            *(u32x4_t*)(o + 32) = hi;
+                        }
+                    }
+                }
+        } else
+        {
+            auto get = [&](int v, int b, int j) { return acc[v >> 2][v & 3][b][j]; };
+            if (full) store_tile_rows<EPI, TM, 8, true, HAS_BIAS, true, false>(get, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
+            else store_tile_rows<EPI, TM, 8, false, HAS_BIAS, false, false>(get, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
         }
-        if (DBG == 5) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
+        if (STAMP) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
         if (!more) break;
+        if (DBG == 9) {       // static hand-out: the next tile of this workgroup's class
+            __builtin_amdgcn_s_barrier();
+            v = vn;
+            vn = vn + (int)gridDim.x;
+        } else {
         post(before(slot), ticket);
         __builtin_amdgcn_s_barrier();
         v = vn;
         vn = collect(before(slot));
+        }
         cur = nxt;
         after_epilogue = full;
     }
@@ -808,14 +942,14 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 9; ++i) tk[i] = 0;
     }
-    if (DBG == 5 && lane == 0) {     // diagnostic instantiation only: the stamps leave through a buffer of their own
+    if (STAMP && lane == 0) {     // diagnostic instantiations only: the stamps leave through a buffer of their own
         float* o = (float*)ep.out2 + ((size_t)blockIdx.x * 4 + wave) * 8;
         const uint64_t now = __builtin_amdgcn_s_memtime(), wall = __builtin_amdgcn_s_memrealtime();
         o[0] = (float)t_sync; o[1] = (float)t_body; o[2] = (float)(now - t_last); o[3] = (float)t_epi;
         o[4] = (float)(now - t_first);          // shader cycles from the first stage to here
         o[5] = (float)(wall - w_first);         // the same span in ticks of the constant 100 MHz clock
         o[6] = (float)(t_first - t_entry);      // prologue: kernel entry to the first stage (cycles)
-        o[7] = 0.f;
+        o[7] = (float)t_bound;                  // tile hand-over: ticket exchange, barrier, next tile's descriptors
     }
 #endif
 }
