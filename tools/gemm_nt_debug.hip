@@ -32,7 +32,7 @@ extern "C" int va_dbg_gemm_nt_quad(const void* x, const void* w, int64_t M, int6
                                    int dbg, int grid_limit, hipStream_t stream) {
     if (!x || !w || !out || M <= 0 || N % 256 || K % 64 || K < 128) { va_set_error("va_dbg_gemm_nt_quad: bad arguments"); return VA_ERR_INVALID; }
     if ((dbg == 5 || dbg >= 8) && !stamps) { va_set_error("va_dbg_gemm_nt_quad: dbg 5 needs a stamp buffer"); return VA_ERR_INVALID; }
-    EpiArgs ep{out, stamps, nullptr, nullptr, nullptr, (int)N, 0u, 0u, 1.f};
+    EpiArgs ep{out, stamps, nullptr, nullptr, nullptr, (int)N, 0u, 0u, 1.f, 1};
     const bf16_t* X = (const bf16_t*)x;
     const bf16_t* W = (const bf16_t*)w;
     const int m = (int)M, n = (int)N, k = (int)K;

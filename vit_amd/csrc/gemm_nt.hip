@@ -27,6 +27,7 @@
 //         buffers, next tile issued before the current tile's MFMAs, vmcnt(0) + barrier per tile.  Used
 //         for small M and short K.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 #include <mutex>
 
@@ -44,6 +45,7 @@ struct EpiArgs {
     // [M, N] matrix: element index m * N + n, so the output must be stored with ldc == N.
     uint32_t drop_key, drop_thi;
     float drop_scale;
+    int nt;               // store the outputs with the non-temporal hint (set by the host from their size)
 };
 
 // keep-or-zero and rescale of `cnt` (even) consecutive elements starting at element index e0 (even)
@@ -164,20 +166,19 @@ VA_DEVINL void unpack_run(typename PackedBf16<NV>::type p, float* v) {
 }
 
 // Epilogue of the 256-wide kernels for the layout above.  get(v, b, j): accumulator register j of 16-row block b and
-// weight block v.  Stores carry the non-temporal hint: the output is read by a later kernel and is hundreds of times the
-// size of an L2, where it would only evict the operand panels that neighbouring tiles are about to re-read (the main loop
-// of the four-wave kernel runs 9 % faster behind such an epilogue).
+// weight block v.  With ep.nt the stores carry the non-temporal hint: an output is hundreds of times the size of an L2,
+// where it only evicts the operand panels that neighbouring tiles are about to re-read (the main loop of the four-wave
+// kernel runs 9 % faster behind such an epilogue) -- but the hint also keeps it out of the last-level cache, where a
+// consumer kernel that starts right after would have found an output of up to about that cache's size; the host sets
+// the flag from the output's size.
 // FULL_M: all of the wave's rows exist, so the row loop carries no branches (a skipped row would make the compiler drain
 // the memory counter in front of every later row's stores).
 // HAS_BIAS = false: the caller knows there is no bias and the adds are left out; true: a null bias pointer adds zeros.
 // RESID_AHEAD: unused (kept so that call sites read the same); the f32 epilogue always requests one row block ahead.
 // CAN_DROP = false compiles the fused-dropout branches out (the four-wave kernel has no registers to spare for them).
-#ifndef VA_NT_16
-#define VA_NT_16 1
-#endif
 template <typename V>
-VA_DEVINL void put_16(V v, V* p) {
-    if (VA_NT_16) __builtin_nontemporal_store(v, p);
+VA_DEVINL void put_16(V v, V* p, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 
@@ -186,7 +187,7 @@ VA_DEVINL void put_16(V v, V* p) {
 // 16-lane row hands its `hi` to the lower half's rows and vice versa (one rotate-by-8 per register, merged by the DPP
 // bank mask), so that one store instruction covers 8 rows x 128 bytes instead of 16 rows x 64.  All 16 rows must exist.
 template <typename V>
-VA_DEVINL void store_line_pairs(char* p, V lo, V hi, int64_t row_bytes, bool upper) {
+VA_DEVINL void store_line_pairs(char* p, V lo, V hi, int64_t row_bytes, bool upper, bool nt) {
     typedef __attribute__((ext_vector_type(4))) int i32x4_t;
     const i32x4_t l = __builtin_bit_cast(i32x4_t, lo), h = __builtin_bit_cast(i32x4_t, hi);
     i32x4_t a, b;
@@ -197,14 +198,20 @@ VA_DEVINL void store_line_pairs(char* p, V lo, V hi, int64_t row_bytes, bool upp
     }
     char* pa = upper ? p + 64 - 8 * row_bytes : p;      // rows 0..7 of the block, both halves of their lines
     char* pb = upper ? p : p + 64 + 8 * row_bytes;      // rows 8..15
-    __builtin_nontemporal_store(a, (i32x4_t*)pa);
-    __builtin_nontemporal_store(b, (i32x4_t*)pb);
+    if (nt) {
+        __builtin_nontemporal_store(a, (i32x4_t*)pa);
+        __builtin_nontemporal_store(b, (i32x4_t*)pb);
+    } else {
+        *(i32x4_t*)pa = a;
+        *(i32x4_t*)pb = b;
+    }
 }
 
 template <int EPI, int TM, int NV, bool FULL_M, bool HAS_BIAS, bool RESID_AHEAD, bool CAN_DROP, typename Get>
 VA_DEVINL void store_tile_rows(Get get, const EpiArgs& ep, int M, int m_wave, int n_wave, int lane) {
     const int ldc = ep.ldc;
     const int r = lane & 15, g = lane >> 4;
+    const bool nt = ep.nt != 0;
     typedef typename PackedBf16<NV>::type pk_t;
     if (EPI == VA_EPI_F32) {
         // weight as the A operand: register q of (v, b) is row b*16 + r, column 16*v + 4*g + q.  The residual values of
@@ -252,7 +259,7 @@ VA_DEVINL void store_tile_rows(Get get, const EpiArgs& ep, int M, int m_wave, in
                     }
                     float* o = (float*)ep.out + (size_t)m * ldc + col(a2);
                     if (FULL_M) {      // blocks a2, a2 + 1 are the two halves of a 128-byte line: whole lines, non-temporal
-                        store_line_pairs((char*)o, res[0], res[1], (int64_t)ldc * 4, (lane & 8) != 0);
+                        store_line_pairs((char*)o, res[0], res[1], (int64_t)ldc * 4, (lane & 8) != 0, nt);
                     } else {
                         *(f32x4_t*)o = res[0];
                         *(f32x4_t*)(o + 16) = res[1];
@@ -291,21 +298,21 @@ VA_DEVINL void store_tile_rows(Get get, const EpiArgs& ep, int M, int m_wave, in
 #pragma unroll
             for (int q = 0; q < NV; ++q) v[q] = HAS_BIAS ? get(q, b, j) + bias[q] : get(q, b, j);
             if (EPI == VA_EPI_BF16) {
-                put_16(pack_run<NV>(v), (pk_t*)((bf16_t*)ep.out + o));
+                put_16(pack_run<NV>(v), (pk_t*)((bf16_t*)ep.out + o), nt);
             } else if (EPI == VA_EPI_BIAS_GELU || EPI == VA_EPI_GELU_ONLY) {
-                if (EPI == VA_EPI_BIAS_GELU) put_16(pack_run<NV>(v), (pk_t*)((bf16_t*)ep.out + o));
+                if (EPI == VA_EPI_BIAS_GELU) put_16(pack_run<NV>(v), (pk_t*)((bf16_t*)ep.out + o), nt);
                 float gl[NV];
 #pragma unroll
                 for (int q = 0; q < NV; ++q) gl[q] = gelu_erf(v[q]);
                 if (CAN_DROP && ep.drop_thi) drop_run<NV>(gl, (uint32_t)o, ep);
-                put_16(pack_run<NV>(gl), (pk_t*)((bf16_t*)(EPI == VA_EPI_BIAS_GELU ? ep.out2 : ep.out) + o));
+                put_16(pack_run<NV>(gl), (pk_t*)((bf16_t*)(EPI == VA_EPI_BIAS_GELU ? ep.out2 : ep.out) + o), nt);
             } else {  // VA_EPI_GELU_BWD
                 float pre[NV], rr[NV];
                 unpack_run<NV>(aux_cur, pre);
 #pragma unroll
                 for (int q = 0; q < NV; ++q) rr[q] = v[q] * gelu_erf_grad(pre[q]);
                 if (CAN_DROP && ep.drop_thi) drop_run<NV>(rr, (uint32_t)o, ep);
-                put_16(pack_run<NV>(rr), (pk_t*)((bf16_t*)ep.out + o));
+                put_16(pack_run<NV>(rr), (pk_t*)((bf16_t*)ep.out + o), nt);
             }
         }
 }
@@ -1100,8 +1107,14 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
     VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || tile == 4256) && N % 256 == 0 && K >= 128),
                  "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
     VA_CHECK_ARG(drop_thresh16 == 0 || tile < 4256, "va_gemm_nt_dropout: the four-wave kernel (tile %d) has no dropout epilogue", tile);
+    // non-temporal stores for outputs beyond the last-level cache's reach (256 MB; VA_GEMM_NT_MIN_MB overrides, 0 = always)
+    static const long nt_min_mb = [] {
+        const char* e = getenv("VA_GEMM_NT_MIN_MB");
+        return e ? atol(e) : 300L;
+    }();
+    const int64_t out_bytes = M * N * (epilogue == VA_EPI_F32 ? 4 : 2) * (epilogue == VA_EPI_BIAS_GELU ? 2 : 1);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc, drop_key, drop_thresh16 << 16,
-               va_drop_scale(drop_thresh16)};
+               va_drop_scale(drop_thresh16), out_bytes >= nt_min_mb * (1ll << 20) ? 1 : 0};
     const bf16_t* X = (const bf16_t*)x;
     const bf16_t* W = (const bf16_t*)w;
     switch (epilogue) {
