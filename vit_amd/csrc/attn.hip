@@ -144,6 +144,32 @@ VA_DEVINL void store_rows(const f32x16_t (&acc)[HD / 32], float mul, bf16_t* out
         }
 }
 
+// The same through a wave-private LDS area (32 rows x (2*HD + 16) bytes): every lane drops its 8-byte pieces there and
+// picks up 16-byte chunks of whole rows, so that a store instruction covers 64 / (HD/8) rows x 2*HD contiguous bytes with
+// neighbouring lanes on neighbouring bytes, instead of 32 rows x two 8-byte pieces from lanes 32 apart.  A store
+// instruction of the scattered shape holds the wave about 290 cycles, one of the contiguous shape about 100 (measured
+// on the GEMM epilogues, tools/quad_epi_prof.py).  out32: row 0 of the 32 rows; all 32 must exist.  LDS operations of one
+// wave execute in order, so no wait is needed between the writes and the reads.
+template <int HD>
+VA_DEVINL void store_rows_lds(const f32x16_t (&acc)[HD / 32], float mul, bf16_t* out32, int64_t ld, char* area, int lane) {
+    constexpr int RS = 2 * HD + 16, CH = HD / 8;          // row stride in the area; 16-byte chunks per row
+    const int row = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int cb = 0; cb < HD / 32; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2_t pk = {pack_bf16x2(acc[cb][4 * g] * mul, acc[cb][4 * g + 1] * mul),
+                          pack_bf16x2(acc[cb][4 * g + 2] * mul, acc[cb][4 * g + 3] * mul)};
+            *(u32x2_t*)(area + row * RS + (cb * 32 + 8 * g + 4 * h) * 2) = pk;
+        }
+#pragma unroll
+    for (int t = 0; t < CH / 2; ++t) {
+        const int r = t * (64 / CH) + lane / CH, c = lane % CH;
+        const u32x4_t v = *(const u32x4_t*)(area + r * RS + c * 16);
+        *(u32x4_t*)(out32 + (int64_t)r * ld + c * 8) = v;
+    }
+}
+
 // Workgroup -> (head, 128-row block).  Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), so
 // taken literally the blocks of one head would land on all 8 XCDs and each XCD's L2 would fetch that head's K / V
 // (or Q / dO) for itself.  The remap hands every XCD a contiguous run of work ids instead: the blocks of a head run
@@ -402,10 +428,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         if (NBUF > 2 && t0 + 2 < nt) tile_step(t0 + 2, std::integral_constant<int, (NBUF > 2 ? 2 : 0)>{});
     }
     l += __shfl_xor(l, 32);
-    if (qrow < N) {
+    // the tiles are done with: the LDS becomes the waves' transposition areas for whole-row stores
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (q0 + 32 <= N)
+        store_rows_lds<HD>(o, (DROP ? drop.scale : 1.0f) / l, O + ((int64_t)b * N + q0) * ldo + hh * HD, ldo,
+                           smem + wave * (32 * (2 * HD + 16)), lane);
+    else if (qrow < N)
         store_rows<HD>(o, (DROP ? drop.scale : 1.0f) / l, O + ((int64_t)b * N + qrow) * ldo + hh * HD, h);
-        if (h == 0) LSE2[(int64_t)bh * N + qrow] = m + __log2f(l);
-    }
+    if (qrow < N && h == 0) LSE2[(int64_t)bh * N + qrow] = m + __log2f(l);
 #ifdef VA_ATTN_PROFILE
     if (lane < 3) LSE2[(int64_t)bh * N + q0 + lane] = (float)pc[lane] / nt;
 #endif
@@ -575,7 +607,14 @@ __global__ __launch_bounds__(256, HD <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
         tile_step(t0, std::integral_constant<int, 0>{});
         if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
     }
-    if (qrow < N) store_rows<HD>(dq, DROP ? scale * drop.scale : scale, DQ + ((int64_t)b * N + qrow) * lddq + hh * HD, h);
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();      // the tiles are done with: the LDS becomes the waves' transposition areas
+    asm volatile("" ::: "memory");
+    if (q0 + 32 <= N)
+        store_rows_lds<HD>(dq, DROP ? scale * drop.scale : scale, DQ + ((int64_t)b * N + q0) * lddq + hh * HD, lddq,
+                           smem + wave * (32 * (2 * HD + 16)), lane);
+    else if (qrow < N)
+        store_rows<HD>(dq, DROP ? scale * drop.scale : scale, DQ + ((int64_t)b * N + qrow) * lddq + hh * HD, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -742,7 +781,14 @@ __global__ __launch_bounds__(256, HD <= 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
         tile_step(t0, std::integral_constant<int, 0>{});
         if (t0 + 1 < nt) tile_step(t0 + 1, std::integral_constant<int, 1>{});
     }
-    if (krow < N) {
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();      // the tiles are done with: the LDS becomes the waves' transposition areas
+    asm volatile("" ::: "memory");
+    if (k0 + 32 <= N) {
+        char* area = smem + wave * (32 * (2 * HD + 16));
+        store_rows_lds<HD>(dk, DROP ? scale * drop.scale : scale, DK + ((int64_t)b * N + k0) * lddq + hh * HD, lddq, area, lane);
+        store_rows_lds<HD>(dv, DROP ? drop.scale : 1.0f, DV + ((int64_t)b * N + k0) * lddq + hh * HD, lddq, area, lane);
+    } else if (krow < N) {
         store_rows<HD>(dk, DROP ? scale * drop.scale : scale, DK + ((int64_t)b * N + krow) * lddq + hh * HD, h);
         store_rows<HD>(dv, DROP ? drop.scale : 1.0f, DV + ((int64_t)b * N + krow) * lddq + hh * HD, h);
     }
@@ -1070,15 +1116,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const bf16_t* __
 #undef TILE_SYNC
     // the asm MFMAs are opaque to the compiler's hazard tracking: let the last results retire before they are read
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // every wave is done with the tiles: the LDS becomes the waves' transposition areas
+    asm volatile("" ::: "memory");
+    char* area = smem + wave * (32 * (2 * HD + 16));
     auto store_sub = [&](auto kb_c) {
         constexpr int kb = decltype(kb_c)::value;
         const f32x16_t dvt[2] = {acc_tile<4 * kb + 0>(), acc_tile<4 * kb + 1>()};
         const f32x16_t dkt[2] = {acc_tile<4 * kb + 2>(), acc_tile<4 * kb + 3>()};
-        const int krow = k0 + kb * 32 + (lane & 31);
-        if (krow < N) {
-            store_rows<HD>(dkt, scale, DK + ((int64_t)b * N + krow) * lddq + hh * HD, h);
-            store_rows<HD>(dvt, 1.0f, DV + ((int64_t)b * N + krow) * lddq + hh * HD, h);
-        }
+        const int64_t row0 = (int64_t)b * N + k0 + kb * 32;      // whole tiles only: all 32 keys exist
+        store_rows_lds<HD>(dkt, scale, DK + row0 * lddq + hh * HD, lddq, area, lane);
+        store_rows_lds<HD>(dvt, 1.0f, DV + row0 * lddq + hh * HD, lddq, area, lane);
     };
     store_sub(std::integral_constant<int, 0>{});
     store_sub(std::integral_constant<int, 1>{});
