@@ -891,17 +891,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const bf16_t* __
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NSL][STAGE] | 16 zero bytes
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Every workgroup does the same work, so the CUs would run their prologue loads (K, V and three tiles: 115 KiB) and
-    // their epilogue stores (64 KiB) all at the same moments, launch after launch of workgroups, at a fraction of the
-    // rate a lone CU gets.  The workgroups of the first round -- one per CU -- therefore start up to ~10k cycles apart;
-    // the CUs keep that phase for the rest of the launch.
-    {
-        const unsigned first_round = blockIdx.y * gridDim.x + blockIdx.x;
-        if (first_round < 256u) {
-            const int naps = (int)((first_round * 37u) & 63u);
-            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(2);          // ~160 cycles each
-        }
-    }
     const HeadBlock hb = head_block();
     const int bh = hb.bh, b = bh / H, hh = bh % H;
     const int k0 = hb.blk * 256 + wave * 64;
@@ -911,20 +900,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const bf16_t* __
     const bf16_t* DOb = DO + (int64_t)b * N * ldo + hh * HD;
     const u32x4_t* aux_b = AUX + (int64_t)bh * N;
 
-    // stationary operands as loaded (the key fragments carry the softmax scale); they move to accumulation registers
-    // further down, once the first tiles are on their way
-    bf16x8_t kf0[2][KS], vf0[2][KS];
-    bf16x8_t kf[2][KS], vf[2][KS];               // ... and where the MFMAs take them from
+    // stationary operands as loaded: whole rows, 8 lanes per 128-byte row (piece t of sub-block kb: key 8t + lane/8,
+    // 16-byte chunk lane%8); they are re-cut into MFMA fragments -- and land in accumulation registers -- further down,
+    // once the first tiles are on their way
+    u32x4_t kraw[2][4], vraw[2][4];
+    bf16x8_t kf[2][KS], vf[2][KS];               // where the MFMAs take them from (the key fragments carry the softmax scale)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int krow = k0 + kb * 32 + (lane & 31);
-        const int krow_c = krow < N ? krow : N - 1;
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf0[kb][ks] = *(const bf16x8_t*)(Kb + (int64_t)krow_c * ld + ks * 16 + h * 8);
-            vf0[kb][ks] = *(const bf16x8_t*)(Vb + (int64_t)krow_c * ld + ks * 16 + h * 8);
+        for (int t = 0; t < 4; ++t) {
+            const int krow = k0 + kb * 32 + 8 * t + (lane >> 3);
+            const int krow_c = krow < N ? krow : N - 1;
+            kraw[kb][t] = *(const u32x4_t*)(Kb + (int64_t)krow_c * ld + (lane & 7) * 8);
+            vraw[kb][t] = *(const u32x4_t*)(Vb + (int64_t)krow_c * ld + (lane & 7) * 8);
         }
-    }
     // A query's record {-lse2 as three bf16 terms + 0 | -delta likewise} is the A operand of the first MFMA of BOTH
     // chains as it stands: the B operand selects the half that counts, 1.0 at k = 0..2 for the scores and at k = 4..6
     // for dP (lane half 0 holds k = 0..7), zero everywhere else.
@@ -1024,23 +1013,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const bf16_t* __
     stage(nt > 2 ? 2 : nt - 1, 2);
     // The stationary fragments belong in accumulation registers (the vector half is needed for scores and packed
     // operands), and a value only gets there without a copy in front of every use when the instruction that DEFINES it
-    // writes there: an LDS read can, a conversion cannot.  So they take one round trip through this wave's 4 KiB of the
-    // fourth ring slot (free until the first step's load), four fragments at a time, while the tiles are in flight.
+    // writes there: an LDS read can, a conversion cannot.  So the rows loaded above go through this wave's 4 KiB of the
+    // fourth ring slot (free until the first step's load), one 32-key sub-block of one operand at a time, while the
+    // tiles are in flight: written as rows (chunk index XOR row index: no bank conflicts either way), read back as the
+    // fragments -- key lane%32, chunk 2*ks + lane/32.  LDS operations of one wave execute in order.
     {
-        char* scr = smem + 3 * STAGE + wave * 4096 + lane * 16;
+        char* area = smem + 3 * STAGE + wave * 4096;
+        const int wr = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);            // + t * 1024
+        const int rr = lane & 31;
+        auto rd = [&](int ks) { return area + rr * 128 + ((((2 * ks + h) ^ rr) & 7) << 4); };
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) *(bf16x8_t*)(scr + ks * 1024) = scale_frag(kf0[kb][ks], c);
+            for (int t = 0; t < 4; ++t)
+                *(bf16x8_t*)(area + t * 1024 + wr) = scale_frag(__builtin_bit_cast(bf16x8_t, kraw[kb][t]), c);
             DKV_PIN0;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const bf16x8_t*)(scr + ks * 1024);
+            for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const bf16x8_t*)rd(ks);
             DKV_PIN0;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) *(bf16x8_t*)(scr + ks * 1024) = vf0[kb][ks];
+            for (int t = 0; t < 4; ++t) *(u32x4_t*)(area + t * 1024 + wr) = vraw[kb][t];
             DKV_PIN0;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) vf[kb][ks] = *(const bf16x8_t*)(scr + ks * 1024);
+            for (int ks = 0; ks < KS; ++ks) vf[kb][ks] = *(const bf16x8_t*)rd(ks);
             DKV_PIN0;
         }
     }
