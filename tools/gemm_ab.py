@@ -14,10 +14,12 @@ from vit_amd import _lib  # noqa: E402
 dev = torch.device("cuda:0")
 BF16, F32 = torch.bfloat16, torch.float32
 M, D = int(os.environ.get("AB_M", "65536")), 1024
-EPI = {"bf16": 0, "bias+gelu": 1, "f32+bias+resid": 2, "xgelu'": 3, "gelu-only": 4}
+EPI = {"bf16": 0, "bias+gelu": 1, "f32+bias+resid": 2, "f32+bias": 2, "xgelu'": 3, "gelu-only": 4}
 CASES = [("qkv", 3 * D, D, "bf16"), ("out", D, D, "f32+bias+resid"), ("fc1", 4 * D, D, "bias+gelu"), ("fc1", 4 * D, D, "gelu-only"),
          ("fc2", D, 4 * D, "f32+bias+resid"), ("dact", 4 * D, D, "xgelu'"), ("dln2", D, 4 * D, "bf16"), ("dattn", D, D, "bf16"),
-         ("dln1", D, 3 * D, "bf16")]
+         ("dln1", D, 3 * D, "bf16"), ("out", D, D, "f32+bias"), ("out", D, D, "bf16")]
+if os.environ.get("AB_CASES"):
+    CASES = [c for c in CASES if any(k in c[0] + ":" + c[3] for k in os.environ["AB_CASES"].split(","))]
 
 
 def bind(path):
