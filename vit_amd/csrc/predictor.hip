@@ -678,7 +678,7 @@ extern "C" int va_dwconv1d_causal_silu_bf16(const void* x_bf16, int64_t ldx, con
     VA_CHECK_ARG(((uintptr_t)x_bf16 | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out) % 16 == 0,
                  "va_dwconv1d_causal_silu_bf16: misaligned operand");
     VA_CHECK_ARG(B * L < (1ll << 33) && L < (1ll << 31), "va_dwconv1d_causal_silu_bf16: problem too large");
-    constexpr int RUN = 4;
+    constexpr int RUN = 8;      // measured at 64 x 2451 rows: 8 steps per wave 260 us, 4: 293, 2: 363, 12 / 16: 303-307
     const int64_t runs = B * ((L + RUN - 1) / RUN);
     hipLaunchKernelGGL((dwconv_silu_bf16_kernel<RUN>), dim3((unsigned)((runs + 3) / 4)), dim3(256), 0, stream,
                        (const bf16_t*)x_bf16, ldx, w, bias, out, runs, (int)L, normalize);
