@@ -253,6 +253,32 @@ int va_ema_update(float* target, const float* online, void* target_bf16, int64_t
 int va_l1_loss(const void* pred, const void* target, int in_bf16, float* loss_sum, void* grad, int grad_bf16,
                float grad_scale, int64_t n, va_stream_t stream);
 
+/* ---- loss heads of the stage-1 step (stage1_surgvu_pretraining.py:426-462): value AND gradient per call ----------
+ * All f32, fixed summation orders (bitwise reproducible), gradients for an upstream gradient of 1.
+ * va_infonce_sym (s1:434-446): z = rows of p1 / p2 divided by max(|row|, 1e-12) when normalize != 0 (F.normalize), else
+ *   the rows as they are; logits = z1 z2^T / temperature;
+ *   loss[0] = 0.5 * (cross_entropy(logits, arange(B)) + cross_entropy(logits^T, arange(B)));  g1, g2 [B, D] its gradient
+ *   with respect to p1, p2 (through the normalisation when normalize != 0).  workspace: va_infonce_workspace_floats(B, D).
+ * va_normalize_rows_fwd / _bwd (s1:434-435, F.normalize(., dim=1)): z = p / max(|p|, 1e-12) per row and inv = that factor;
+ *   dp = (dz - z (z . dz)) * inv.  The same arithmetic as va_infonce_sym's built-in normalisation: a data-parallel step
+ *   normalises locally, gathers z over the ranks and calls va_infonce_sym with normalize = 0 on the global batch.
+ * va_cross_entropy (s1:428): logits f32 [B, C], labels int64 [B]; loss[0] = mean_b (logsumexp - logit[label]);
+ *   dlogits [B, C] = (softmax - onehot) * grad_scale: 1/B is the gradient of the mean; a caller that will multiply by an
+ *   upstream factor g passes 1 and applies g/B itself -- one rounding, whatever B and g are.  workspace: B floats.
+ * va_mse_loss (s1:459): loss[0] = mean((x - y)^2) over n elements; dx = (x - y) * grad_scale (2/n for the gradient of the
+ *   mean; y is a target: no gradient).  workspace: va_mse_workspace_floats(n) floats. */
+int va_normalize_rows_fwd(const float* p, float* z, float* inv, int64_t B, int64_t D, va_stream_t stream);
+int va_normalize_rows_bwd(const float* dz, const float* z, const float* inv, float* dp, int64_t B, int64_t D,
+                          va_stream_t stream);
+int64_t va_infonce_workspace_floats(int64_t B, int64_t D);
+int va_infonce_sym(const float* p1, const float* p2, float* loss, float* g1, float* g2, float* workspace, int64_t B,
+                   int64_t D, float temperature, int normalize, va_stream_t stream);
+int va_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, float* workspace, int64_t B,
+                     int64_t C, float grad_scale, va_stream_t stream);
+int64_t va_mse_workspace_floats(int64_t n);
+int va_mse_loss(const float* x, const float* y, float* loss, float* dx, float* workspace, int64_t n, float grad_scale,
+                va_stream_t stream);
+
 /* ---- predictor: gated delta-rule memory (GatedDeltaLayer, swm:431-555), inference form -----------------
  * Sequential recurrence of _sequential_gated_delta (swm:523-555) for every (batch, head):
  *   S <- alpha_t * S * (I - beta_t k_t k_t^T) + beta_t v_t k_t^T ;  out_t = S q_t

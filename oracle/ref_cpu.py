@@ -422,6 +422,14 @@ def stage1_losses(f_shuf, f_orig, f_aug, enc_tokens, order_label, heads: Dict[st
     return l_t + l_c + lambda_mask * l_m, (l_t, l_c, l_m)
 
 
+def infonce_sym(p1, p2, temperature: float = 0.07, normalize: bool = True):
+    """Symmetric InfoNCE of two (B, D) projection sets (s1:437-446): rows normalised (F.normalize) unless they come
+    normalised, logits = z1 z2^T / tau, 0.5 * (CE(logits, diag) + CE(logits^T, diag))."""
+    z1, z2 = (F.normalize(p1, dim=1), F.normalize(p2, dim=1)) if normalize else (p1, p2)
+    lab = torch.arange(z1.shape[0])
+    return 0.5 * (F.cross_entropy(z1 @ z2.t() / temperature, lab) + F.cross_entropy(z2 @ z1.t() / temperature, lab))
+
+
 def encoder_flops_per_clip(depth: int, n_tokens: int, dim: int = 1024, patch_k: int = 1536) -> float:
     """Forward FLOPs of one clip: per token per layer 2*D*3D + 2*D*D + 2*2*D*4D + 4*N*D, plus patch embed."""
     per_tok = 2 * dim * 3 * dim + 2 * dim * dim + 4 * dim * 4 * dim + 4 * n_tokens * dim

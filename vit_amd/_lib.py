@@ -70,6 +70,13 @@ SIGNATURES = {
     "va_dwconv1d_causal_silu": (ci, [vp, vp, vp, vp, i64, i64, i64, ci, vp]),
     "va_gate_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, i64, i64, cf, vp]),
     "va_dwconv1d_causal_silu_bf16": (ci, [vp, i64, vp, vp, vp, i64, i64, i64, ci, vp]),
+    "va_normalize_rows_fwd": (ci, [vp, vp, vp, i64, i64, vp]),
+    "va_normalize_rows_bwd": (ci, [vp, vp, vp, vp, i64, i64, vp]),
+    "va_infonce_workspace_floats": (i64, [i64, i64]),
+    "va_infonce_sym": (ci, [vp, vp, vp, vp, vp, vp, i64, i64, cf, ci, vp]),
+    "va_cross_entropy": (ci, [vp, vp, vp, vp, vp, i64, i64, cf, vp]),
+    "va_mse_workspace_floats": (i64, [i64]),
+    "va_mse_loss": (ci, [vp, vp, vp, vp, vp, i64, cf, vp]),
     "va_delta_gates_fwd": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     "va_gate_layernorm_fwd_g16": (ci, [vp, vp, vp, i64, vp, vp, vp, i64, i64, cf, vp]),
 }

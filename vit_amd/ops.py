@@ -440,6 +440,74 @@ def gate_layernorm_fwd(o, gate, g, gamma, beta, out, eps: float = 1e-5):
     return out
 
 
+# ------------------------------------------------------------------ loss heads (value and gradient per call)
+def infonce_sym(p1: torch.Tensor, p2: torch.Tensor, temperature: float, normalize: bool = True):
+    """Symmetric InfoNCE of two [B, D] f32 projection sets (s1:434-446).  Returns (loss [1], dloss/dp1, dloss/dp2)."""
+    _need(p1, F32, "p1"); _need(p2, F32, "p2")
+    if p1.dim() != 2 or p1.shape != p2.shape or not (p1.is_contiguous() and p2.is_contiguous()):
+        raise ValueError("infonce_sym: p1, p2 must be contiguous [B, D] of one shape")
+    B, D = p1.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.va_infonce_workspace_floats(B, D), dtype=F32, device=p1.device)
+    loss = torch.empty(1, dtype=F32, device=p1.device)
+    g1, g2 = torch.empty_like(p1), torch.empty_like(p2)
+    check(lib.va_infonce_sym(_p(p1), _p(p2), _p(loss), _p(g1), _p(g2), _p(ws), B, D, float(temperature), int(bool(normalize)),
+                             _stream()), "va_infonce_sym")
+    return loss, g1, g2
+
+
+def normalize_rows(p: torch.Tensor):
+    """F.normalize(p, dim=1) of a contiguous f32 [B, D] matrix -> (z, inv), inv [B] the factor applied to each row."""
+    _need(p, F32, "p")
+    if p.dim() != 2 or not p.is_contiguous():
+        raise ValueError("normalize_rows: p must be a contiguous matrix")
+    B, D = p.shape
+    z, inv = torch.empty_like(p), torch.empty(B, dtype=F32, device=p.device)
+    check(_lib.load().va_normalize_rows_fwd(_p(p), _p(z), _p(inv), B, D, _stream()), "va_normalize_rows_fwd")
+    return z, inv
+
+
+def normalize_rows_bwd(dz: torch.Tensor, z: torch.Tensor, inv: torch.Tensor):
+    _need(dz, F32, "dz"); _need(z, F32, "z"); _need(inv, F32, "inv")
+    if dz.shape != z.shape or not (dz.is_contiguous() and z.is_contiguous()) or inv.numel() != z.shape[0]:
+        raise ValueError("normalize_rows_bwd: inconsistent shapes")
+    dp = torch.empty_like(z)
+    check(_lib.load().va_normalize_rows_bwd(_p(dz), _p(z), _p(inv), _p(dp), z.shape[0], z.shape[1], _stream()),
+          "va_normalize_rows_bwd")
+    return dp
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Optional[float] = None):
+    """Mean cross-entropy of [B, C] f32 logits against int64 labels (s1:428).  Returns (loss [1], (softmax - onehot) *
+    grad_scale); grad_scale None = 1/B, the gradient of the mean."""
+    _need(logits, F32, "logits")
+    if logits.dim() != 2 or not logits.is_contiguous() or labels.dtype != torch.int64 or labels.shape != logits.shape[:1] \
+            or not labels.is_cuda or not labels.is_contiguous():
+        raise ValueError("cross_entropy: logits contiguous [B, C] f32, labels contiguous int64 [B] on the device")
+    B, C = logits.shape
+    ws = torch.empty(B, dtype=F32, device=logits.device)
+    loss = torch.empty(1, dtype=F32, device=logits.device)
+    dx = torch.empty_like(logits)
+    check(_lib.load().va_cross_entropy(_p(logits), _p(labels), _p(loss), _p(dx), _p(ws), B, C,
+                                       1.0 / B if grad_scale is None else float(grad_scale), _stream()), "va_cross_entropy")
+    return loss, dx
+
+
+def mse_loss(x: torch.Tensor, y: torch.Tensor, grad_scale: Optional[float] = None):
+    """mean((x - y)^2) (s1:459).  Returns (loss [1], (x - y) * grad_scale); grad_scale None = 2/n, the gradient of the mean."""
+    _need(x, F32, "x"); _need(y, F32, "y")
+    if x.shape != y.shape or not (x.is_contiguous() and y.is_contiguous()):
+        raise ValueError("mse_loss: x, y must be contiguous and of one shape")
+    n = x.numel()
+    lib = _lib.load()
+    ws = torch.empty(lib.va_mse_workspace_floats(n), dtype=F32, device=x.device)
+    loss = torch.empty(1, dtype=F32, device=x.device)
+    dx = torch.empty_like(x)
+    check(lib.va_mse_loss(_p(x), _p(y), _p(loss), _p(dx), _p(ws), n, 2.0 / n if grad_scale is None else float(grad_scale),
+                          _stream()), "va_mse_loss")
+    return loss, dx
+
+
 def delta_gates_fwd(x2d, wa, wb):
     """alpha, beta = sigmoid(x @ wa^T), sigmoid(x @ wb^T): x f32 [M, 1024]; wa, wb f32 [H, 1024] -> two f32 [M, H]
     (swm:494-495)."""

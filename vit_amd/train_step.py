@@ -4,7 +4,8 @@
 (stage1_surgvu_pretraining.py:418-470; frozen-encoder variant stage1_vjepa2_finetuning.py:281-339):
 order classification on a shuffled clip, symmetric InfoNCE between a clip and its augmentation, and the
 masked-mean denoising term on a no-grad pass, `loss = L_t + L_c + lambda * L_m`, global-norm clip 1.0, AdamW.
-The heads are tiny (B x 1024 MLPs) and stay ordinary torch modules; the encoder passes are the HIP path.
+The heads' layers are tiny (B x 1024 MLPs) and stay ordinary torch modules; the three loss formulas on top of them
+(value and gradient) are one kernel call each, and the encoder passes are the HIP path.
 
 `jepa_latent_step` is the composite that exercises the token-gather, L1 and EMA kernels at full size; the
 reference has no such objective (its "JEPA" is the three terms above).
@@ -97,6 +98,99 @@ def _pool_unmasked(tokens: torch.Tensor, num_temporal_patches: int, mask_ratio: 
     return ops.token_pool(t, n_first), ops.token_pool(t)
 
 
+class _InfoNCE(torch.autograd.Function):
+    """0.5 * (CE(z1 z2^T / tau) + CE(z2 z1^T / tau)) with z = normalised rows (s1:434-446): value and both gradients from
+    one kernel call in the forward; the backward scales them."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, temperature, normalize):
+        loss, g1, g2 = ops.infonce_sym(p1.detach().contiguous(), p2.detach().contiguous(), temperature, normalize)
+        ctx.save_for_backward(g1, g2)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g1, g2 = ctx.saved_tensors
+        return g1 * g, g2 * g, None, None
+
+
+class _NormalizeRows(torch.autograd.Function):
+    """F.normalize(p, dim=1) on the kernels (the arithmetic of the fused InfoNCE's own normalisation)."""
+
+    @staticmethod
+    def forward(ctx, p):
+        z, inv = ops.normalize_rows(p.detach().contiguous())
+        ctx.save_for_backward(z, inv)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        z, inv = ctx.saved_tensors
+        return ops.normalize_rows_bwd(dz.contiguous(), z, inv)
+
+
+def normalize_rows(p):
+    return _NormalizeRows.apply(p) if _on_kernels(p) and p.dim() == 2 else F.normalize(p, dim=1)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    """The kernel leaves (softmax - onehot) unscaled; the backward applies (upstream / B) as ONE factor, so that a mean
+    over a shard times the shard's weight rounds like the mean over the whole batch."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, d = ops.cross_entropy(logits.detach().contiguous(), labels.contiguous(), grad_scale=1.0)
+        ctx.save_for_backward(d)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        # (a float tensor divided by a Python number is multiplied by the rounded reciprocal: the division is done in f64)
+        return d * (g.double() / d.shape[0]).to(d.dtype), None
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        loss, d = ops.mse_loss(x.detach().contiguous(), y.detach().contiguous(), grad_scale=1.0)
+        ctx.save_for_backward(d)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        return d * (g.double() * 2.0 / d.numel()).to(d.dtype), None
+
+
+def _on_kernels(*tensors) -> bool:
+    """Device f32 tensors take the loss kernels; anything else (the CPU rehearsals of the data-parallel step) the same
+    formulas in torch."""
+    return all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def infonce(p1, p2, temperature: float, normalize: bool = True):
+    """Symmetric InfoNCE of two [B, D] projection sets; on the device one fused kernel call (value + gradients), else
+    the formula in torch."""
+    if _on_kernels(p1, p2) and p1.shape[0] <= 8192 and p1.shape[1] <= 2048:
+        return _InfoNCE.apply(p1, p2, temperature, normalize)
+    z1, z2 = (F.normalize(p1, dim=1), F.normalize(p2, dim=1)) if normalize else (p1, p2)
+    labels = torch.arange(z1.shape[0], device=z1.device)
+    return 0.5 * (F.cross_entropy(z1 @ z2.t() / temperature, labels) + F.cross_entropy(z2 @ z1.t() / temperature, labels))
+
+
+def cross_entropy(logits, labels):
+    if _on_kernels(logits) and labels.is_cuda and labels.dtype == torch.int64:
+        return _CrossEntropy.apply(logits, labels)
+    return F.cross_entropy(logits, labels)
+
+
+def mse(x, y):
+    if _on_kernels(x, y) and not y.requires_grad and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
+        return _Mse.apply(x, y)
+    return F.mse_loss(x, y)
+
+
 def stage1_head_losses(heads: Stage1Heads, f_shuf, f_orig, f_aug, pooled_unmasked, pooled_all, order_label,
                        lambda_mask: float = 0.1, temperature: float = 0.07,
                        group: Optional[dist.ProcessGroup] = None):
@@ -108,21 +202,23 @@ def stage1_head_losses(heads: Stage1Heads, f_shuf, f_orig, f_aug, pooled_unmaske
     ranks the InfoNCE negatives span the global batch (projections are all-gathered), and the objective is scaled
     so that the rank-AVERAGED gradient equals the one-rank gradient on the concatenated batch: the gathered term
     -- identical on every rank -- times world, the per-rank means times (B_local / B_global) * world."""
-    l_t = F.cross_entropy(heads.temporal_classifier(f_shuf), order_label)
-    z1 = F.normalize(heads.contrastive_proj(f_orig), dim=1)
-    z2 = F.normalize(heads.contrastive_proj(f_aug), dim=1)
-    world, b_local = 1, z1.shape[0]
+    l_t = cross_entropy(heads.temporal_classifier(f_shuf), order_label)
+    p1, p2 = heads.contrastive_proj(f_orig), heads.contrastive_proj(f_aug)
+    world, b_local, b_global = 1, p1.shape[0], p1.shape[0]
+    # rows are normalised locally; with several ranks the negatives span the global batch (the normalised rows are
+    # gathered); the loss kernel takes normalised rows as they are -- the same arithmetic for any number of ranks
+    z1, z2 = normalize_rows(p1), normalize_rows(p2)
     if group is not None or (dist.is_initialized() and dist.get_world_size() > 1):
         world = dist.get_world_size(group)
         z1, z2 = all_gather_with_grad(z1, group), all_gather_with_grad(z2, group)
-    labels = torch.arange(z1.shape[0], device=z1.device)
-    l_c = 0.5 * (F.cross_entropy(z1 @ z2.t() / temperature, labels) + F.cross_entropy(z2 @ z1.t() / temperature, labels))
+        b_global = z1.shape[0]
+    l_c = infonce(z1, z2, temperature, normalize=False)
 
     l_m = torch.zeros((), device=f_orig.device)
     if heads.denoise_head is not None and pooled_unmasked is not None:
-        l_m = F.mse_loss(heads.denoise_head(pooled_unmasked), pooled_all)
+        l_m = mse(heads.denoise_head(pooled_unmasked), pooled_all)
     if world > 1:
-        w = shard_weight(b_local, z1.shape[0], world)
+        w = shard_weight(b_local, b_global, world)
         objective = w * (l_t + lambda_mask * l_m) + world * l_c
     else:
         objective = l_t + l_c + lambda_mask * l_m
