@@ -313,9 +313,10 @@ int va_gate_layernorm_fwd_g16(const float* o, const float* gate, const void* g_b
 
 /* The layer's two per-head gates, alpha = sigmoid(x @ wa^T) and beta = sigmoid(x @ wb^T) (swm:448-449, 494-495; the
  * projections have no bias): x f32 [M, D] contiguous, D = 1024; wa, wb f32 [H, D], H <= 8; alpha, beta f32 [M, H].
- * f32 products and sums; a row's summation order does not depend on its position in the batch. */
-int va_delta_gates_fwd(const float* x, const float* wa, const float* wb, float* alpha, float* beta, int64_t M, int64_t D,
-                       int64_t H, va_stream_t stream);
+ * f32 products and sums; a row's summation order does not depend on its position in the batch.  x_bf16 (optional, may be
+ * NULL): bf16 [M, D] copy of x, written by the same pass (the operand of the layer's projection GEMM). */
+int va_delta_gates_fwd(const float* x, const float* wa, const float* wb, float* alpha, float* beta, void* x_bf16, int64_t M,
+                       int64_t D, int64_t H, va_stream_t stream);
 
 /* ---- input pipeline: the tensor side of the reference's per-frame transform (ToTensor + Normalize,
  * stage1_surgvu_pretraining.py:241-244, 279-286) ---------------------------------------------------------

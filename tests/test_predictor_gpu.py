@@ -180,8 +180,10 @@ def test_delta_gates_vs_torch(env, M, H):
     x = R.hashed_uniform("t.ab.x", (M, 1024), 2.0)
     wa = R.hashed_uniform("t.ab.wa", (H, 1024), 0.06)
     wb = R.hashed_uniform("t.ab.wb", (H, 1024), 0.06)
-    alpha, beta = ops.delta_gates_fwd(x.cuda(), wa.cuda(), wb.cuda())
+    xb = torch.empty(M, 1024, dtype=torch.bfloat16, device="cuda")
+    alpha, beta = ops.delta_gates_fwd(x.cuda(), wa.cuda(), wb.cuda(), xb)
     assert alpha.shape == (M, H) and beta.shape == (M, H)
+    assert torch.equal(xb.cpu(), x.bfloat16())                    # the cast of x that the same pass writes
     ref_a = torch.sigmoid(x.double() @ wa.double().t()).float()
     ref_b = torch.sigmoid(x.double() @ wb.double().t()).float()
     assert (alpha.cpu() - ref_a).abs().max().item() < 2e-6 and (beta.cpu() - ref_b).abs().max().item() < 2e-6

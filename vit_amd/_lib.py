@@ -77,7 +77,7 @@ SIGNATURES = {
     "va_cross_entropy": (ci, [vp, vp, vp, vp, vp, i64, i64, cf, vp]),
     "va_mse_workspace_floats": (i64, [i64]),
     "va_mse_loss": (ci, [vp, vp, vp, vp, vp, i64, cf, vp]),
-    "va_delta_gates_fwd": (ci, [vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    "va_delta_gates_fwd": (ci, [vp, vp, vp, vp, vp, vp, i64, i64, i64, vp]),
     "va_gate_layernorm_fwd_g16": (ci, [vp, vp, vp, i64, vp, vp, vp, i64, i64, cf, vp]),
 }
 

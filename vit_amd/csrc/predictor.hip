@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ 
 constexpr int ABG_D = 1024, ABG_ROWS = 4;
 __global__ __launch_bounds__(256) void ab_gate_kernel(const float* __restrict__ X, const float* __restrict__ WA,
                                                       const float* __restrict__ WB, float* __restrict__ ALPHA,
-                                                      float* __restrict__ BETA, int64_t M, int H) {
+                                                      float* __restrict__ BETA, bf16_t* __restrict__ XB, int64_t M, int H) {
     extern __shared__ __align__(16) float abw[];          // [16][1024]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 16 * ABG_D / 4; i += 256) {
@@ -542,6 +542,9 @@ __global__ __launch_bounds__(256) void ab_gate_kernel(const float* __restrict__ 
             for (int r = 0; r < ABG_ROWS; ++r) {
                 const int64_t row = row0 + r < M ? row0 + r : M - 1;
                 xv[r] = *(const f32x4_t*)(X + row * ABG_D + q * 256 + lane * 4);
+                // the bf16 copy of x that the projection GEMM takes, made from the values this pass reads anyway
+                if (XB != nullptr && row0 + r < M)
+                    *(u32x2_t*)(XB + row * ABG_D + q * 256 + lane * 4) = (u32x2_t){pack_bf16x2(xv[r][0], xv[r][1]), pack_bf16x2(xv[r][2], xv[r][3])};
             }
 #pragma unroll
             for (int o = 0; o < 16; ++o) {
@@ -575,13 +578,14 @@ __global__ __launch_bounds__(256) void ab_gate_kernel(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int va_delta_gates_fwd(const float* x, const float* wa, const float* wb, float* alpha, float* beta, int64_t M,
-                                  int64_t D, int64_t H, hipStream_t stream) {
+extern "C" int va_delta_gates_fwd(const float* x, const float* wa, const float* wb, float* alpha, float* beta, void* x_bf16,
+                                  int64_t M, int64_t D, int64_t H, hipStream_t stream) {
     VA_CHECK_ARG(x && wa && wb && alpha && beta, "va_delta_gates_fwd: null operand");
     VA_CHECK_ARG(D == ABG_D, "va_delta_gates_fwd: width %lld not supported (1024)", (long long)D);
     VA_CHECK_ARG(H >= 1 && H <= 8, "va_delta_gates_fwd: %lld heads not supported (1..8)", (long long)H);
     VA_CHECK_ARG(M > 0 && M < (1ll << 33), "va_delta_gates_fwd: row count out of range");
-    VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)wa | (uintptr_t)wb) % 16 == 0, "va_delta_gates_fwd: misaligned operand");
+    VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)wa | (uintptr_t)wb) % 16 == 0 && (uintptr_t)x_bf16 % 8 == 0,
+                 "va_delta_gates_fwd: misaligned operand");
     static bool lds_ok = false;
     constexpr int lds = 16 * ABG_D * 4;
     if (!lds_ok) {
@@ -593,7 +597,7 @@ extern "C" int va_delta_gates_fwd(const float* x, const float* wa, const float* 
     }
     const int64_t blocks_wanted = (M + 4 * ABG_ROWS - 1) / (4 * ABG_ROWS);
     const unsigned grid = (unsigned)(blocks_wanted < 512 ? blocks_wanted : 512);
-    hipLaunchKernelGGL(ab_gate_kernel, dim3(grid), dim3(256), lds, stream, x, wa, wb, alpha, beta, M, (int)H);
+    hipLaunchKernelGGL(ab_gate_kernel, dim3(grid), dim3(256), lds, stream, x, wa, wb, alpha, beta, (bf16_t*)x_bf16, M, (int)H);
     VA_CHECK_LAUNCH("va_delta_gates_fwd");
     return VA_OK;
 }

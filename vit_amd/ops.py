@@ -508,9 +508,9 @@ def mse_loss(x: torch.Tensor, y: torch.Tensor, grad_scale: Optional[float] = Non
     return loss, dx
 
 
-def delta_gates_fwd(x2d, wa, wb):
+def delta_gates_fwd(x2d, wa, wb, x_bf16=None):
     """alpha, beta = sigmoid(x @ wa^T), sigmoid(x @ wb^T): x f32 [M, 1024]; wa, wb f32 [H, 1024] -> two f32 [M, H]
-    (swm:494-495)."""
+    (swm:494-495).  x_bf16: optional contiguous bf16 [M, 1024] that receives the cast of x from the same pass."""
     _need(x2d, F32, "x"); _need(wa, F32, "wa"); _need(wb, F32, "wb")
     M, D = x2d.shape
     H = wa.shape[0]
@@ -519,7 +519,11 @@ def delta_gates_fwd(x2d, wa, wb):
         raise ValueError("delta_gates_fwd: inconsistent shapes")
     alpha = torch.empty(M, H, dtype=F32, device=x2d.device)
     beta = torch.empty(M, H, dtype=F32, device=x2d.device)
-    check(_lib.load().va_delta_gates_fwd(_p(x2d), _p(wa), _p(wb), _p(alpha), _p(beta), M, D, H, _stream()),
+    if x_bf16 is not None:
+        _need(x_bf16, BF16, "x_bf16")
+        if tuple(x_bf16.shape) != (M, D) or not x_bf16.is_contiguous():
+            raise ValueError("delta_gates_fwd: x_bf16 must be contiguous [M, D]")
+    check(_lib.load().va_delta_gates_fwd(_p(x2d), _p(wa), _p(wb), _p(alpha), _p(beta), _p(x_bf16), M, D, H, _stream()),
           "va_delta_gates_fwd")
     return alpha, beta
 

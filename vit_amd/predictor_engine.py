@@ -61,15 +61,16 @@ def block_forward(blk, x: torch.Tensor, tokens_per_timestep: int, state: Optiona
         t = blk.temporal_layer
         Hd, Dh = t.num_heads, t.head_dim
         inner = Hd * Dh
-        xb = ops.cast_bf16(x_mid)
+        # the two gate projections and, from the same pass over x, its bf16 copy for the projection GEMM
+        xb = new(D, BF16)
+        alpha, beta = ops.delta_gates_fwd(x_mid, t.a_proj.weight.detach(), t.b_proj.weight.detach(), xb)
+        alpha, beta = alpha.view(B, L, Hd), beta.view(B, L, Hd)
         # q, k, v (value half and gate half, swm:500) and g as ONE product against the stacked weights; every kernel
         # that follows reads its 1024-wide column block of the bf16 result in place
         proj = new(5 * inner, BF16)
         ops.gemm_nt(xb, wc.fwd_cat("qkvg_proj", (t.q_proj.weight, t.k_proj.weight, t.v_proj.weight, t.g_proj.weight)),
                     ops.EPI_BF16, proj)
         conv_w, conv_b = t.v_conv1d.weight.detach().reshape(2 * inner, 4), t.v_conv1d.bias.detach()
-        alpha, beta = ops.delta_gates_fwd(x_mid, t.a_proj.weight.detach(), t.b_proj.weight.detach())
-        alpha, beta = alpha.view(B, L, Hd), beta.view(B, L, Hd)
 
         def col(i):
             return proj[:, i * inner:(i + 1) * inner]
