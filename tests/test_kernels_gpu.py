@@ -226,7 +226,10 @@ def attn_reference(qkv, B, N, H):
 @pytest.mark.parametrize("B,N,H", [(2, 8, 16), (1, 200, 16), (2, 1568, 16), (1, 2048, 16), (2, 18, 8), (1, 300, 8),
                                    (1, 1024, 8), (1, 8192, 16), (1, 8200, 8),   # the last two: 64-frame clips
                                    (2, 8, 32), (1, 300, 32), (1, 2048, 32),      # 32 heads: head dim 32
-                                   (3, 1, 16), (2, 33, 8), (1, 65, 16), (2, 127, 32), (1, 129, 16)])   # around the tile edges
+                                   (3, 1, 16), (2, 33, 8), (1, 65, 16), (2, 127, 32), (1, 129, 16),   # around the tile edges
+                                   (3, 64, 16), (2, 192, 16), (2, 320, 16), (2, 128, 8), (2, 64, 32)])  # whole 64-row tiles, but
+                                   # fewer keys than a backward workgroup covers: several clips, so a store past a clip's
+                                   # last key would land in the next clip's rows
 def test_attention_fwd_bwd(ops, dev, B, N, H):
     D = 1024
     qkv = rnd((B * N, 3 * D), dev, 11, dtype=BF16)

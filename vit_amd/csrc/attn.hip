@@ -1118,9 +1118,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const bf16_t* __
         constexpr int kb = decltype(kb_c)::value;
         const f32x16_t dvt[2] = {acc_tile<4 * kb + 0>(), acc_tile<4 * kb + 1>()};
         const f32x16_t dkt[2] = {acc_tile<4 * kb + 2>(), acc_tile<4 * kb + 3>()};
-        const int64_t row0 = (int64_t)b * N + k0 + kb * 32;      // whole tiles only: all 32 keys exist
-        store_rows_lds<HD>(dkt, scale, DK + row0 * lddq + hh * HD, lddq, area, lane);
-        store_rows_lds<HD>(dvt, 1.0f, DV + row0 * lddq + hh * HD, lddq, area, lane);
+        // N is a whole number of 64-query tiles, not of this workgroup's 256 keys: a sub-block may lie (wholly) past N
+        const int key0 = k0 + kb * 32, krow = key0 + (lane & 31);
+        if (key0 + 32 <= N) {
+            const int64_t row0 = (int64_t)b * N + key0;
+            store_rows_lds<HD>(dkt, scale, DK + row0 * lddq + hh * HD, lddq, area, lane);
+            store_rows_lds<HD>(dvt, 1.0f, DV + row0 * lddq + hh * HD, lddq, area, lane);
+        } else if (krow < N) {
+            store_rows<HD>(dkt, scale, DK + ((int64_t)b * N + krow) * lddq + hh * HD, h);
+            store_rows<HD>(dvt, 1.0f, DV + ((int64_t)b * N + krow) * lddq + hh * HD, h);
+        }
     };
     store_sub(std::integral_constant<int, 0>{});
     store_sub(std::integral_constant<int, 1>{});
