@@ -85,7 +85,8 @@ int va_tubelet_scatter(const float* patches, float* video, int64_t B, int64_t C,
                        int64_t tt, int64_t th, int64_t tw, va_stream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm, eps 1e-6; swm:686, 695, 757) ---------------------------------------
- * forward: x f32 [M,D] -> y (bf16 if out_bf16 else f32) [M,D]; also stores mean/rstd [M] for backward. */
+ * forward: x f32 [M,D] -> y (bf16 if out_bf16 else f32) [M,D]; also stores mean/rstd [M] for backward (both NULL: a
+ * forward-only call that keeps no statistics). */
 int va_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_bf16, float* mean,
                      float* rstd, int64_t M, int64_t D, float eps, va_stream_t stream);
 /* backward: dy (bf16 if dy_bf16 else f32) [M,D]; dx_out(f32) = (resid_grad ? resid_grad : 0) + dLN/dx;

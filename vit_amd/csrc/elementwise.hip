@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             ss += d * d;
         }
     const float rs = rsqrtf(wave_sum(ss) * (1.0f / LN_D) + eps);
-    if (lane == 0) {
+    if (lane == 0 && mean != nullptr) {      // a forward that keeps nothing for a backward passes no statistics buffers
         mean[row] = mu;
         rstd[row] = rs;
     }
@@ -692,7 +692,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const TIN* __restrict__ in
 // ===================================================================================================
 extern "C" int va_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
                                 float* mean, float* rstd, int64_t M, int64_t D, float eps, hipStream_t stream) {
-    VA_CHECK_ARG(x && gamma && beta && y && mean && rstd, "va_layernorm_fwd: null operand");
+    VA_CHECK_ARG(x && gamma && beta && y, "va_layernorm_fwd: null operand");
+    VA_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "va_layernorm_fwd: mean and rstd go together (both, or neither for a forward-only call)");
     VA_CHECK_ARG(D == LN_D, "va_layernorm_fwd: width %lld not supported (the encoder is 1024 wide)", (long long)D);
     VA_CHECK_ARG(M > 0, "va_layernorm_fwd: empty input");
     VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, "va_layernorm_fwd: misaligned operand");

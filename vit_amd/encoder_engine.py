@@ -281,7 +281,9 @@ class EncoderEngine:
             x = x_next
 
         y = new(D, F32)
-        mean_f, rstd_f = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
+        mean_f = rstd_f = None
+        if save:
+            mean_f, rstd_f = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
         ops.layernorm_fwd(x, P["norm.weight"], P["norm.bias"], y, mean_f, rstd_f, LN_EPS)
         if save:
             ctx.x_last, ctx.mean_f, ctx.rstd_f = x, mean_f, rstd_f
@@ -310,12 +312,8 @@ class EncoderEngine:
             return t
 
         def stat(name):
-            if keep:
-                return torch.empty(M, dtype=F32, device=dev)
-            t = scratch.get(name)
-            if t is None:
-                t = scratch[name] = torch.empty(M, dtype=F32, device=dev)
-            return t
+            # LayerNorm statistics exist for the backward only: a pass that keeps nothing does not have them written
+            return torch.empty(M, dtype=F32, device=dev) if keep else None
 
         mean1, rstd1 = stat("mean1"), stat("rstd1")
         ln1 = buf("ln1", D, BF16)

@@ -175,16 +175,19 @@ def tubelet_scatter(patches: torch.Tensor, video_shape, tubelet: Tuple[int, int,
 
 
 # ------------------------------------------------------------------ LayerNorm
-def layernorm_fwd(x, gamma, beta, out, mean, rstd, eps: float = 1e-6):
+def layernorm_fwd(x, gamma, beta, out, mean=None, rstd=None, eps: float = 1e-6):
     _need(x, F32, "x"); _need(gamma, F32, "gamma"); _need(beta, F32, "beta")
     M, D = x.shape
     if not (x.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (M, D)):
         raise ValueError("layernorm_fwd: x/out must be contiguous [M,D]")
     if out.dtype not in (BF16, F32):
         raise TypeError("layernorm_fwd: out must be bf16 or f32")
-    _need(mean, F32, "mean"); _need(rstd, F32, "rstd")
-    if mean.numel() != M or rstd.numel() != M:
-        raise ValueError("layernorm_fwd: mean/rstd must have M elements")
+    if (mean is None) != (rstd is None):
+        raise ValueError("layernorm_fwd: mean and rstd go together (both None for a forward that keeps no statistics)")
+    if mean is not None:
+        _need(mean, F32, "mean"); _need(rstd, F32, "rstd")
+        if mean.numel() != M or rstd.numel() != M:
+            raise ValueError("layernorm_fwd: mean/rstd must have M elements")
     check(_lib.load().va_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(out), int(out.dtype == BF16), _p(mean), _p(rstd),
                                        M, D, eps, _stream()), "va_layernorm_fwd")
     return out

@@ -44,9 +44,8 @@ def block_forward(blk, x: torch.Tensor, tokens_per_timestep: int, state: Optiona
     def new(cols, dtype):
         return torch.empty(M, cols, dtype=dtype, device=dev)
 
-    mean, rstd = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
     ln = new(D, BF16)
-    ops.layernorm_fwd(x2, blk.norm1.weight, blk.norm1.bias, ln, mean, rstd, blk.norm1.eps)
+    ops.layernorm_fwd(x2, blk.norm1.weight, blk.norm1.bias, ln, eps=blk.norm1.eps)       # inference: no statistics kept
     qkv = new(3 * D, BF16)
     ops.gemm_nt(ln, wc.fwd("in_proj", a.in_proj_weight), ops.EPI_BF16, qkv, bias=a.in_proj_bias.detach())
     attn = new(D, BF16)
@@ -90,7 +89,7 @@ def block_forward(blk, x: torch.Tensor, tokens_per_timestep: int, state: Optiona
         ops.gemm_nt(on, wc.fwd("o_proj", t.o_proj.weight), ops.EPI_F32, x_dn, resid=x_mid)
         x_mid = x_dn
 
-    ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, ln, mean, rstd, blk.norm2.eps)
+    ops.layernorm_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, ln, eps=blk.norm2.eps)
     act = new(4 * D, BF16)
     ops.gemm_nt(ln, wc.fwd("fc1", blk.mlp[0].weight), ops.EPI_GELU_ONLY, act, bias=blk.mlp[0].bias.detach())
     x_out = new(D, F32)
@@ -140,8 +139,7 @@ def sequential_forward(seq, x: torch.Tensor, wc: WeightCache, name: str) -> torc
                 and i + 1 < len(mods) and linear_supported(mods[i + 1])):
             M = cur.shape[0]
             ln = torch.empty(M, 1024, dtype=BF16, device=cur.device)
-            mean, rstd = torch.empty(M, dtype=F32, device=cur.device), torch.empty(M, dtype=F32, device=cur.device)
-            ops.layernorm_fwd(cur.contiguous(), m.weight.detach(), m.bias.detach(), ln, mean, rstd, m.eps)
+            ops.layernorm_fwd(cur.contiguous(), m.weight.detach(), m.bias.detach(), ln, eps=m.eps)
             cur = ln
         else:
             cur = m(cur)
