@@ -58,6 +58,17 @@ int va_gemm_nt_dropout(const void* x, const void* w, int64_t M, int64_t N, int64
                        int epilogue, void* out, void* out2, const float* bias, const float* resid, const void* aux,
                        int64_t ldc, int tile, uint32_t key, float p, va_stream_t stream);
 
+/* The QKV projection of an attention block with the 3-D rotary embedding applied in the GEMM's epilogue
+ * (RoPEMultiheadAttention.forward, swm:300-308 followed by apply_rope_to_qk, swm:265-281), for the encoder's regular token
+ * grid:  out (bf16 [M, 3072], q | k | v) = rope(x[M, K] w[3072, K]^T), the rotation as va_rope3d_qk_inplace applies it
+ * to the q and k thirds, but on the f32 accumulators (the two-pass route rotates the bf16-rounded product).
+ * tables: the [cos | sin] tables of va_rope3d_qk_inplace for the grid (Tp, Hp, Wp); pos_code int32 [M]: per output row
+ * t | h << 10 | w << 20, its token's grid coordinates (each < 1024).  M >= 256, K a multiple of 64 and >= 192.
+ * Runs on the persistent four-wave kernel only: VA_ERR_UNSUPPORTED_SHAPE when that kernel has no ticket set left for the
+ * stream (callers then take va_gemm_nt + va_rope3d_qk_inplace). */
+int va_gemm_nt_qkv_rope(const void* x, const void* w, int64_t M, int64_t K, int64_t ldx, int64_t ldw, void* out, int64_t ldc,
+                        const float* tables, const int32_t* pos_code, int64_t Tp, int64_t Hp, int64_t Wp, va_stream_t stream);
+
 /* dw[N,K] (f32) += dy[M,N]^T * x[M,K]: the weight-gradient half of nn.Linear's backward (autograd of
  * swm:296, 334, 698-701, 102).  bf16 operands, split over M in `split_k` slices (0 = choose; negative =
  * |split_k| slices on the small-tile kernel) that are

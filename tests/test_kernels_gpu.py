@@ -223,6 +223,48 @@ def attn_reference(qkv, B, N, H):
     return o, lse2.reshape(B * H, N)
 
 
+@pytest.mark.parametrize("B,grid", [(2, (8, 16, 16)), (1, (4, 24, 22)), (3, (8, 16, 16)), (2, (5, 20, 30))])
+def test_qkv_projection_with_the_rotation_in_its_epilogue(ops, dev, B, grid):
+    """va_gemm_nt_qkv_rope against the two-pass route (va_gemm_nt, then va_rope3d_qk_inplace) and against the f32
+    formula: the fused kernel rotates the f32 accumulators, the two-pass route the rounded product, so they differ by
+    bf16 roundings; the value third is untouched by the rotation and must be bit-identical."""
+    Tp, Hp, Wp = grid
+    N = Tp * Hp * Wp
+    M, K = B * N, 1024
+    x = R.hashed_uniform("t.qr.x", (M, K), 1.0).to(dev).to(BF16)
+    w = R.hashed_uniform("t.qr.w", (3072, K), 0.03).to(dev).to(BF16)
+    inv = {k: R.hashed_uniform("t.qr." + k, (n,), 0.5, 0.6) for k, n in (("t", 128), ("h", 192), ("w", 192))}
+    tables = ops.rope_tables_device(inv["t"], inv["h"], inv["w"], grid, 2.0, dev)
+    pos = ops.rope_pos_code(B, grid, dev)
+    fused = torch.full((M, 3072), float("nan"), dtype=BF16, device=dev)
+    assert ops.gemm_nt_qkv_rope(x, w, fused, tables, pos, grid)
+    two = torch.empty(M, 3072, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_BF16, two)
+    plain = two.clone()
+    ops.rope3d_qk_(two, tables, grid)
+    assert torch.isfinite(fused.float()).all()
+    assert torch.equal(fused[:, 2048:], two[:, 2048:])
+    # f32 formula: rotate the unrounded product with the same tables
+    y = x.float() @ w.float().t()
+    Tsz = Tp * 128 + (Hp + Wp) * 192
+    cos, sin = tables[:Tsz], tables[Tsz:]
+    n = torch.arange(M, device=dev) % N
+    tt, hh, ww = n // (Hp * Wp), (n // Wp) % Hp, n % Wp
+    ref = y.clone()
+    for part in (0, 1024):
+        for a0, half, cnt, tab in ((0, 128, 128, tt * 128), (256, 192, 192, Tp * 128 + hh * 192), (640, 192, 192, Tp * 128 + Hp * 192 + ww * 192)):
+            idx = tab[:, None] + torch.arange(cnt, device=dev)[None, :]
+            c, sn = cos[idx], sin[idx]
+            a, b = y[:, part + a0:part + a0 + cnt], y[:, part + a0 + half:part + a0 + half + cnt]
+            ref[:, part + a0:part + a0 + cnt] = a * c - b * sn
+            ref[:, part + a0 + half:part + a0 + half + cnt] = b * c + a * sn
+    assert rel_err(fused, ref) < 3e-3, rel_err(fused, ref)
+    assert rel_err(two, ref) < 5e-3
+    assert rel_err(fused, ref) <= rel_err(two, ref)                 # one rounding instead of two
+    assert rel_err(fused[:, :2048], two[:, :2048]) < 6e-3
+    assert not torch.equal(plain[:, :2048], two[:, :2048])          # (the rotation did something)
+
+
 @pytest.mark.parametrize("B,N,H", [(2, 8, 16), (1, 200, 16), (2, 1568, 16), (1, 2048, 16), (2, 18, 8), (1, 300, 8),
                                    (1, 1024, 8), (1, 8192, 16), (1, 8200, 8),   # the last two: 64-frame clips
                                    (2, 8, 32), (1, 300, 32), (1, 2048, 32),      # 32 heads: head dim 32

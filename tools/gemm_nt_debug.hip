@@ -8,7 +8,7 @@
 //   dbg 6  operands fetched as whole lines into registers and dropped       dbg 7  the same + one ds_write_b128 each
 //   dbg 8  stamps + epilogue without its stores         dbg 9  stamps + static tile hand-out (no ticket atomics)
 //   dbg 10 stamps + epilogue that stores zeros without reading the accumulators
-//   dbg 11-16  as 10 with other store shapes (see the kernel)
+//   dbg 11-17  as 10 with other store shapes (see the kernel)
 // Build (done by the tools that use it): hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared
 //                                        -I vit_amd/csrc -I include tools/gemm_nt_debug.hip -o tools/libva_gemm_debug.so
 #include <cstdarg>
@@ -32,7 +32,7 @@ extern "C" int va_dbg_gemm_nt_quad(const void* x, const void* w, int64_t M, int6
                                    int dbg, int grid_limit, hipStream_t stream) {
     if (!x || !w || !out || M <= 0 || N % 256 || K % 64 || K < 128) { va_set_error("va_dbg_gemm_nt_quad: bad arguments"); return VA_ERR_INVALID; }
     if ((dbg == 5 || dbg >= 8) && !stamps) { va_set_error("va_dbg_gemm_nt_quad: dbg 5 needs a stamp buffer"); return VA_ERR_INVALID; }
-    EpiArgs ep{out, stamps, nullptr, nullptr, nullptr, (int)N, 0u, 0u, 1.f, 1};
+    EpiArgs ep{out, stamps, nullptr, nullptr, nullptr, (int)N, 0u, 0u, 1.f, 1, nullptr, nullptr, 0, 0, 0};
     const bf16_t* X = (const bf16_t*)x;
     const bf16_t* W = (const bf16_t*)w;
     const int m = (int)M, n = (int)N, k = (int)K;
@@ -53,6 +53,7 @@ extern "C" int va_dbg_gemm_nt_quad(const void* x, const void* w, int64_t M, int6
         case 14: return launch_quad<VA_EPI_BF16, false, 14>(X, W, m, n, k, k, k, ep, stream, grid_limit);
         case 15: return launch_quad<VA_EPI_BF16, false, 15>(X, W, m, n, k, k, k, ep, stream, grid_limit);
         case 16: return launch_quad<VA_EPI_BF16, false, 16>(X, W, m, n, k, k, k, ep, stream, grid_limit);
+        case 17: return launch_quad<VA_EPI_BF16, false, 17>(X, W, m, n, k, k, k, ep, stream, grid_limit);
     }
     va_set_error("va_dbg_gemm_nt_quad: unknown variant %d", dbg);
     return VA_ERR_INVALID;

@@ -17,7 +17,7 @@ for name in (sys.argv[1:] or ["qkv", "fc2"]):
     Nn, K = SHAPES[name]
     x = torch.randn(M, K, device=dev).to(torch.bfloat16); w = (torch.randn(Nn, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
     out = torch.zeros(M, Nn, dtype=torch.bfloat16, device=dev)
-    for dbg in (5, 9, 8, 10, 11, 12, 13, 14, 15, 16):
+    for dbg in [int(v) for v in os.environ.get("EPI_VARIANTS", "5,9,8,10,11,12,13,14,15,16,17").split(",")]:
         stamps = torch.zeros(grid * 4 * 8, dtype=torch.float32, device=dev)
         s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
         for _ in range(300): G.gemm(lib, x, w, out, dbg=dbg, grid_limit=grid, stamps=stamps)

@@ -72,6 +72,7 @@ SIGNATURES = {
     "va_dwconv1d_causal_silu_bf16": (ci, [vp, i64, vp, vp, vp, i64, i64, i64, ci, vp]),
     "va_normalize_rows_fwd": (ci, [vp, vp, vp, i64, i64, vp]),
     "va_normalize_rows_bwd": (ci, [vp, vp, vp, vp, i64, i64, vp]),
+    "va_gemm_nt_qkv_rope": (ci, [vp, vp, i64, i64, i64, i64, vp, i64, vp, vp, i64, i64, i64, vp]),
     "va_infonce_workspace_floats": (i64, [i64, i64]),
     "va_infonce_sym": (ci, [vp, vp, vp, vp, vp, vp, i64, i64, cf, ci, vp]),
     "va_cross_entropy": (ci, [vp, vp, vp, vp, vp, i64, i64, cf, vp]),

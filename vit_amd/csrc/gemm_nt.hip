@@ -46,7 +46,12 @@ struct EpiArgs {
     uint32_t drop_key, drop_thi;
     float drop_scale;
     int nt;               // store the outputs with the non-temporal hint (set by the host from their size)
+    // QKV projection with the rotary embedding applied in the epilogue (EPI_QKV_ROPE, four-wave kernel only):
+    const float* rope_tables;      // [cos | sin] tables of va_rope3d_qk_inplace
+    const int32_t* rope_pos;       // per output row: t | h << 10 | w << 20
+    int rope_tp, rope_hp, rope_wp;
 };
+constexpr int EPI_QKV_ROPE = 100;      // internal epilogue code: reached through va_gemm_nt_qkv_rope only
 
 // keep-or-zero and rescale of `cnt` (even) consecutive elements starting at element index e0 (even)
 template <int CNT>
@@ -315,6 +320,88 @@ VA_DEVINL void store_tile_rows(Get get, const EpiArgs& ep, int M, int m_wave, in
                 put_16(pack_run<NV>(rr), (pk_t*)((bf16_t*)ep.out + o), nt);
             }
         }
+}
+
+// Epilogue of the fused QKV projection + 3-D rotary embedding (swm:265-281 on the output of swm:300-308).  The 3072 output
+// columns are q | k | v; inside q and inside k, column c of the time segment [0, 256) rotates with c + 128, column 256 + i
+// of the height segment [256, 640) with 448 + i, column 640 + i of the width segment [640, 1024) with 832 + i.  The
+// kernel stages the weight rows so that a wave owns 64 such pairs -- 64 consecutive "first" columns from a0 on and their 64
+// partners from b0 on -- and lane r the four pairs a0 + 4r .. + 3: its accumulator values 0..3 of an output row are the
+// first columns, 4..7 the partners, and the rotation needs no other lane.  The value third of the output takes the same
+// path with cos = 1, sin = 0 left out (plain stores of two 4-column pieces).  toff: the lane's offset into a position's
+// table row, or -1 for the value third.  Rotation in f32 on the accumulators (the separate pass rotates the rounded
+// bf16 product): y_a = a cos - b sin, y_b = b cos + a sin.
+template <int TM, bool FULL_M, typename Get>
+VA_DEVINL void store_tile_qkv_rope(Get get, const EpiArgs& ep, int M, int m_wave, int col_a, int col_b, int seg, int seg_off,
+                                   int lane) {
+    const int ldc = ep.ldc;
+    const int r = lane & 15, g = lane >> 4;
+    const bool nt = ep.nt != 0;
+    const int tab_sz = ep.rope_tp * 128 + (ep.rope_hp + ep.rope_wp) * 192;
+    const bool rot = seg >= 0;
+    // every row's table offset first (one 4-byte load per row, all in flight together), then the table rows one output row
+    // ahead of their use: a load issued after a store would wait for that store too (memory operations retire in order)
+    const int base = seg == 0 ? 0 : seg == 1 ? ep.rope_tp * 128 : ep.rope_tp * 128 + ep.rope_hp * 192;
+    const int stride = seg == 0 ? 128 : 192, shift = seg == 0 ? 0 : seg == 1 ? 10 : 20;
+    int toff[TM * 4];
+#pragma unroll
+    for (int i = 0; i < TM * 4; ++i) {
+        const int m = m_wave + (i >> 2) * 16 + 4 * g + (i & 3);
+        toff[i] = 0;
+        if (rot && (FULL_M || m < M)) toff[i] = ep.rope_pos[m];
+    }
+#pragma unroll
+    for (int i = 0; i < TM * 4; ++i) toff[i] = base + ((toff[i] >> shift) & 1023) * stride + seg_off + 4 * r;
+    f32x4_t cs_next = {1.f, 1.f, 1.f, 1.f}, sn_next = {0.f, 0.f, 0.f, 0.f};
+    if (rot) {
+        cs_next = *(const f32x4_t*)(ep.rope_tables + toff[0]);
+        sn_next = *(const f32x4_t*)(ep.rope_tables + tab_sz + toff[0]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM * 4; ++i) {
+        const int b = i >> 2, j = i & 3;
+        const int m = m_wave + b * 16 + 4 * g + j;
+        const f32x4_t cs = cs_next, sn = sn_next;
+        if (rot && i + 1 < TM * 4) {
+            cs_next = *(const f32x4_t*)(ep.rope_tables + toff[i + 1]);
+            sn_next = *(const f32x4_t*)(ep.rope_tables + tab_sz + toff[i + 1]);
+        }
+        if (!FULL_M && m >= M) continue;
+        float a[4], bb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = get(q, b, j); bb[q] = get(4 + q, b, j); }
+        if (rot) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float ya = a[q] * cs[q] - bb[q] * sn[q];
+                const float yb = bb[q] * cs[q] + a[q] * sn[q];
+                a[q] = ya;
+                bb[q] = yb;
+            }
+        }
+        bf16_t* o = (bf16_t*)ep.out + (size_t)m * ldc;
+        put_16((u32x2_t){pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])}, (u32x2_t*)(o + col_a + 4 * r), nt);
+        put_16((u32x2_t){pack_bf16x2(bb[0], bb[1]), pack_bf16x2(bb[2], bb[3])}, (u32x2_t*)(o + col_b + 4 * r), nt);
+    }
+}
+
+// Where the 64 pairs of half-tile (nt, wn) of the fused QKV + rotary kernel lie: first columns from a0, partners from b0
+// (columns of the 3072-wide output), segment 0 / 1 / 2 = time / height / width (-1: the value third, no rotation), and the
+// offset of a0 inside its segment's table row.
+VA_DEVINL void qkv_rope_cols(int nt, int wn, int& a0, int& b0, int& seg, int& seg_off) {
+    const int part = nt >> 2, pair0 = (nt & 3) * 128 + wn * 64;     // q / k / v; first of the 64 pairs (of 512 per part)
+    if (part == 2) {
+        a0 = 2048 + (nt & 3) * 256 + wn * 128;
+        b0 = a0 + 64;
+        seg = -1;
+        seg_off = 0;
+    } else if (pair0 < 128) {
+        a0 = part * 1024 + pair0; b0 = a0 + 128; seg = 0; seg_off = pair0;
+    } else if (pair0 < 320) {
+        a0 = part * 1024 + 256 + (pair0 - 128); b0 = a0 + 192; seg = 1; seg_off = pair0 - 128;
+    } else {
+        a0 = part * 1024 + 640 + (pair0 - 320); b0 = a0 + 192; seg = 2; seg_off = pair0 - 320;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,7 +736,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 
     // diagnostic instantiations: 5 stamps only; 8 stamps + epilogue without its stores; 9 stamps + tiles assigned
     // statically (no ticket atomics); 10 stamps + epilogue that stores without reading the accumulators
-    constexpr bool STAMP = DBG == 5 || (DBG >= 8 && DBG <= 16);
+    constexpr bool STAMP = DBG == 5 || (DBG >= 8 && DBG <= 17);
     const uint64_t t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -663,9 +750,11 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     // tile's first row, sized to the rows that exist so that rows past M read as zero), a per-thread byte offset
     // that is the same for every tile (1024 chunks per operand per stage, 4 per thread: chunk q -> row q>>2,
     // slot q&3), and the stage's k offset as the scalar offset.
+    constexpr bool ROPE = EPI == EPI_QKV_ROPE;
     struct Tile {
         int m0, n0;
         __amdgpu_buffer_rsrc_t x, w;
+        int sw[4];        // ROPE: byte offset of the weight rows behind load i (the tile's rows come from four ranges)
     };
     auto set_tile = [&](int v, Tile& t) {
         int mt, nt;
@@ -675,21 +764,37 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         const int64_t xb = (int64_t)(M - t.m0) * ldx * 2, wb = (int64_t)(N - t.n0) * ldw * 2;
         t.x = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (size_t)t.m0 * ldx), (short)0,
                                                 (int)(xb < 0x7fffffff ? xb : 0x7fffffff), 0x00020000);
-        t.w = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)t.n0 * ldw), (short)0,
-                                                (int)(wb < 0x7fffffff ? wb : 0x7fffffff), 0x00020000);
+        if (ROPE) {
+            // weight rows of load i: LDS rows [64 i, 64 i + 64) = wave column half i >> 1, first columns (i even) or
+            // partners (i odd); the descriptor spans the whole matrix
+            const int64_t all = (int64_t)N * ldw * 2;
+            t.w = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, (int)(all < 0x7fffffff ? all : 0x7fffffff), 0x00020000);
+#pragma unroll
+            for (int hw = 0; hw < 2; ++hw) {
+                int a0, b0, seg, so;
+                qkv_rope_cols(nt, hw, a0, b0, seg, so);
+                t.sw[2 * hw] = a0 * ldw * 2;
+                t.sw[2 * hw + 1] = b0 * ldw * 2;
+            }
+        } else {
+            t.w = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)t.n0 * ldw), (short)0,
+                                                    (int)(wb < 0x7fffffff ? wb : 0x7fffffff), 0x00020000);
+        }
     };
     int xvo[4], wvo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = i * NT + tid, row = q >> 2, c = (q & 3) ^ (((row >> 3) & 1) * 3);
         xvo[i] = (row * ldx + c * 8) * 2;
-        wvo[i] = (wide_wrow<EPI, 128>(row) * ldw + c * 8) * 2;
+        // ROPE: LDS row (v, r) of a 64-row range holds weight row 4 r + (v & 3) of that range (see store_tile_qkv_rope)
+        wvo[i] = ROPE ? ((4 * (row & 15) + ((row >> 4) & 3)) * ldw + c * 8) * 2 : (wide_wrow<EPI, 128>(row) * ldw + c * 8) * 2;
     }
     // load i (0..7) of stage kt of tile t into ring slot `slot`: X chunks first, then W chunks
     auto load_one = [&](const Tile& t, int kt, int slot, int i) {
         char* base = smem + slot * STAGE_BYTES + (i >> 2) * OP_BYTES + ((i & 3) * NT + wave * 64) * 16;
         __builtin_amdgcn_raw_ptr_buffer_load_lds((i >> 2) ? t.w : t.x, (lds_ptr_t)base, 16,
-                                                 (i >> 2) ? wvo[i & 3] : xvo[i & 3], kt * BK * 2, 0, 0);
+                                                 (i >> 2) ? wvo[i & 3] : xvo[i & 3],
+                                                 kt * BK * 2 + ((ROPE && (i >> 2)) ? t.sw[i & 3] : 0), 0, 0);
     };
 
     const int frow = lane & 15;
@@ -731,9 +836,12 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 #pragma unroll
             for (int j = 0; j < 8; ++j) sink[i][j] = (u32x4_t){0u, 0u, 0u, 0u};
     }
-    auto body = [&](auto parity, auto first, int next_slot, const Tile& lt, int kt_load, int load_slot) {
+    auto body = [&](auto parity, auto first, int next_slot, const Tile& lt, int kt_load, int load_slot, auto prefetch) {
         constexpr int P = decltype(parity)::value;
         constexpr bool FIRST = decltype(first)::value;
+        // PREFETCH false (the last stage of a tile in the fused QKV + rotary build): the next tile's first fragments are
+        // read after the epilogue instead -- that epilogue needs the 128 registers they would occupy across it
+        constexpr bool PREFETCH = decltype(prefetch)::value;
         auto block = [&](auto bc) {
             constexpr int b = decltype(bc)::value;
 #pragma unroll
@@ -742,7 +850,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
                 else mf(acc[0][a][b], wf[P][a], xf[b]);
             }
             VA_PIN;
-            if (DBG != 2) wf[P ^ 1][b] = frag_w(next_slot, b);
+            if (DBG != 2 && PREFETCH) wf[P ^ 1][b] = frag_w(next_slot, b);
             VA_PIN;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -750,7 +858,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
                 else mf(acc[1][a][b], wf[P][4 + a], xf[b]);
             }
             VA_PIN;
-            if (DBG != 2) xf[b] = frag_x(next_slot, b);
+            if (DBG != 2 && PREFETCH) xf[b] = frag_x(next_slot, b);
             if (DBG == 6 || DBG == 7) {
                 // timing only: the stage's bytes fetched as whole 128-byte lines into registers (8 lanes per row) instead
                 // of 64-byte half lines into LDS; DBG 7 also writes the registers of the previous stage's loads into the slot
@@ -850,19 +958,28 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         set_tile(vn < tiles ? vn : v, nxt);
         if (STAMP) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_bound += now - t_last; t_last = now; }
         // stage kt issues the loads of stage kt+4: of this tile, or of the next one from its stage 0 on
-        auto stage_one = [&](auto parity, auto first, int kt, bool relaxed) {
+        auto stage_one = [&](auto parity, auto first, int kt, bool relaxed, auto prefetch) {
             const bool in_cur = kt + 4 < nk;
             sync(relaxed);
-            body(parity, first, advance(slot), in_cur ? cur : nxt, in_cur ? kt + 4 : kt + 4 - nk, before(slot));
+            body(parity, first, advance(slot), in_cur ? cur : nxt, in_cur ? kt + 4 : kt + 4 - nk, before(slot), prefetch);
             slot = advance(slot);
         };
-        stage_one(P0{}, Yes{}, 0, after_epilogue);
-        stage_one(P1{}, No{}, 1, after_epilogue);
-        stage_one(P0{}, No{}, 2, after_epilogue);
-        stage_one(P1{}, No{}, 3, false);
-        for (int kt = 4; kt < nk; kt += 2) {
-            stage_one(P0{}, No{}, kt, false);
-            stage_one(P1{}, No{}, kt + 1, false);
+        stage_one(P0{}, Yes{}, 0, after_epilogue, Yes{});
+        stage_one(P1{}, No{}, 1, after_epilogue, Yes{});
+        stage_one(P0{}, No{}, 2, after_epilogue, Yes{});
+        stage_one(P1{}, No{}, 3, false, Yes{});
+        if constexpr (ROPE) {      // nk >= 6 (checked by the host): the last stage is peeled off and reads no fragments ahead
+            for (int kt = 4; kt + 2 < nk; kt += 2) {
+                stage_one(P0{}, No{}, kt, false, Yes{});
+                stage_one(P1{}, No{}, kt + 1, false, Yes{});
+            }
+            stage_one(P0{}, No{}, nk - 2, false, Yes{});
+            stage_one(P1{}, No{}, nk - 1, false, No{});
+        } else {
+            for (int kt = 4; kt < nk; kt += 2) {
+                stage_one(P0{}, No{}, kt, false, Yes{});
+                stage_one(P1{}, No{}, kt + 1, false, Yes{});
+            }
         }
 
         // the asm MFMAs are opaque to the compiler's hazard tracking: let the last results retire before they are read
@@ -871,7 +988,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         const bool more = vn < tiles;
         const int ticket = (more && DBG != 9) ? draw() : 0;
         const bool full = cur.m0 + wm * 128 + 128 <= M;
-        if (DBG >= 11 && DBG <= 16) {
+        if (DBG >= 11 && DBG <= 17) {
             // timing only: the same 32 KiB per wave stored from zeroed registers in other shapes -- 11: 8 rows x 128 B per
             // instruction, 12: 4 rows x 256 B, 13: as 10 with the non-temporal hint, 14: as 12 with it, 15: 16 rows x 64 B
             // but the two halves of a line 16 instructions apart, 16: 8-byte stores (16 rows x 32 B, 64 instructions)
@@ -886,6 +1003,10 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
                     if (DBG == 13) __builtin_nontemporal_store(z, (u32x4_t*)(base + (size_t)((i >> 2) * 16 + (lane & 15)) * ep.ldc + (i & 3) * 32 + (lane >> 4) * 8));
                     if (DBG == 14) __builtin_nontemporal_store(z, (u32x4_t*)(base + (size_t)(i * 4 + (lane >> 4)) * ep.ldc + (lane & 15) * 8));
                     if (DBG == 15) *(u32x4_t*)(base + (size_t)((i & 7) * 16 + (lane & 15)) * ep.ldc + (i >> 3) * 32 + (lane >> 4) * 8) = z;
+                    if (DBG == 17) {      // 8-byte stores, neighbouring lanes on neighbouring bytes: 4 rows x 128 B per instruction, 64 of them
+                        *(u32x2_t*)(base + (size_t)(i * 4 + (lane >> 4)) * ep.ldc + (lane & 15) * 4) = (u32x2_t){z[0], z[1]};
+                        *(u32x2_t*)(base + (size_t)(i * 4 + (lane >> 4)) * ep.ldc + 64 + (lane & 15) * 4) = (u32x2_t){z[2], z[3]};
+                    }
                     if (DBG == 16) {
                         *(u32x2_t*)(base + (size_t)((i >> 2) * 16 + (lane & 15)) * ep.ldc + (i & 3) * 32 + (lane >> 4) * 4) = (u32x2_t){z[0], z[1]};
                         *(u32x2_t*)(base + (size_t)((i >> 2) * 16 + (lane & 15)) * ep.ldc + (i & 3) * 32 + 16 + (lane >> 4) * 4) = (u32x2_t){z[2], z[3]};
@@ -919,8 +1040,22 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         } else
         {
             auto get = [&](int v, int b, int j) { return acc[v >> 2][v & 3][b][j]; };
-            if (full) store_tile_rows<EPI, TM, 8, true, HAS_BIAS, true, false>(get, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
-            else store_tile_rows<EPI, TM, 8, false, HAS_BIAS, false, false>(get, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
+            if constexpr (ROPE) {
+                // accumulators are copied out where they are used, by statements the compiler keeps in order: left to
+                // itself it copies all 256 out first and spills forty of them around this (register-hungrier) epilogue
+                auto get_here = [&](int v, int b, int j) {
+                    float x;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[v >> 2][v & 3][b][j]));
+                    return x;
+                };
+                int a0, b0, seg, so;
+                qkv_rope_cols(cur.n0 / BN, wn, a0, b0, seg, so);
+                if (full) store_tile_qkv_rope<TM, true>(get_here, ep, M, cur.m0 + wm * 128, a0, b0, seg, so, lane);
+                else store_tile_qkv_rope<TM, false>(get_here, ep, M, cur.m0 + wm * 128, a0, b0, seg, so, lane);
+            } else {
+                if (full) store_tile_rows<EPI, TM, 8, true, HAS_BIAS, true, false>(get, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
+                else store_tile_rows<EPI, TM, 8, false, HAS_BIAS, false, false>(get, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
+            }
         }
         if (STAMP) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_epi += now - t_last; t_last = now; }
         if (!more) break;
@@ -936,6 +1071,12 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         }
         cur = nxt;
         after_epilogue = full;
+        if constexpr (ROPE) {      // the fragments of the next tile's first stage (landed since the last stage's wait + barrier)
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(slot, a);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xf[b] = frag_x(slot, b);
+        }
     }
     wait_vm0();   // the trailing loads must not land in LDS after the workgroup has gone
     if (DBG == 6 || DBG == 7) {
@@ -1056,7 +1197,14 @@ int launch_quad(const bf16_t* X, const bf16_t* W, int M, int N, int K, int ldx, 
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     bool none = false;
     int* tk = quad_ticket_set(dev, stream, &none);
-    if (none) return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
+    if (none) {
+        if constexpr (EPI == EPI_QKV_ROPE) {      // only the four-wave kernel has this epilogue: the caller takes the two-pass route
+            va_set_error("va_gemm_nt_qkv_rope: no ticket set is left for this stream");
+            return VA_ERR_UNSUPPORTED;
+        } else {
+            return launch_ring<EPI, true>(X, W, M, N, K, ldx, ldw, ep, stream);
+        }
+    }
     if (!tk) return VA_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, X, W, M, N, K, ldx, ldw, ep, tk);
     VA_CHECK_LAUNCH("va_gemm_nt");
@@ -1114,7 +1262,7 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
     }();
     const int64_t out_bytes = M * N * (epilogue == VA_EPI_F32 ? 4 : 2) * (epilogue == VA_EPI_BIAS_GELU ? 2 : 1);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc, drop_key, drop_thresh16 << 16,
-               va_drop_scale(drop_thresh16), out_bytes >= nt_min_mb * (1ll << 20) ? 1 : 0};
+               va_drop_scale(drop_thresh16), out_bytes >= nt_min_mb * (1ll << 20) ? 1 : 0, nullptr, nullptr, 0, 0, 0};
     const bf16_t* X = (const bf16_t*)x;
     const bf16_t* W = (const bf16_t*)w;
     switch (epilogue) {
@@ -1156,4 +1304,26 @@ extern "C" int va_gemm_nt_dropout(const void* x, const void* w, int64_t M, int64
         VA_CHECK_ARG(M * N < (1ll << 32), "va_gemm_nt_dropout: more than 2^32 output elements");
     }
     return gemm_nt_entry(x, w, M, N, K, ldx, ldw, epilogue, out, out2, bias, resid, aux, ldc, tile, key, thresh, stream);
+}
+
+extern "C" int va_gemm_nt_qkv_rope(const void* x, const void* w, int64_t M, int64_t K, int64_t ldx, int64_t ldw, void* out,
+                                   int64_t ldc, const float* tables, const int32_t* pos_code, int64_t Tp, int64_t Hp, int64_t Wp,
+                                   hipStream_t stream) {
+    constexpr int64_t N = 3072;
+    VA_CHECK_ARG(x && w && out && tables && pos_code, "va_gemm_nt_qkv_rope: null operand");
+    VA_CHECK_ARG(M >= 256 && M < (1ll << 31) && K >= 192 && K % 64 == 0 && K < (1ll << 20),
+                 "va_gemm_nt_qkv_rope: M=%lld (>= 256) or K=%lld (multiple of 64, >= 192) out of range", (long long)M, (long long)K);
+    VA_CHECK_ARG(ldx >= K && ldw >= K && ldc >= N && ldx % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0,
+                 "va_gemm_nt_qkv_rope: bad leading dimension");
+    VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)tables) % 16 == 0 && (uintptr_t)pos_code % 4 == 0,
+                 "va_gemm_nt_qkv_rope: misaligned operand");
+    VA_CHECK_ARG(Tp > 0 && Hp > 0 && Wp > 0 && Tp < 1024 && Hp < 1024 && Wp < 1024, "va_gemm_nt_qkv_rope: grid out of range");
+    VA_CHECK_ARG(N * ldw * 2 < (1ll << 31), "va_gemm_nt_qkv_rope: weight matrix too large for one descriptor");
+    static const long nt_min_mb = [] {
+        const char* e = getenv("VA_GEMM_NT_MIN_MB");
+        return e ? atol(e) : 300L;
+    }();
+    EpiArgs ep{out, nullptr, nullptr, nullptr, nullptr, (int)ldc, 0u, 0u, 1.f, M * N * 2 >= nt_min_mb * (1ll << 20) ? 1 : 0,
+               tables, pos_code, (int)Tp, (int)Hp, (int)Wp};
+    return launch_quad<EPI_QKV_ROPE, false>((const bf16_t*)x, (const bf16_t*)w, (int)M, (int)N, (int)K, (int)ldx, (int)ldw, ep, stream);
 }

@@ -208,6 +208,14 @@ class EncoderEngine:
         self._tables: Dict[Tuple, torch.Tensor] = {}
 
     # ---------------------------------------------------------------- helpers
+    def rope_pos(self, batch: int, grid, device) -> torch.Tensor:
+        """Per token row its packed grid coordinates (what the fused QKV + rotary GEMM indexes the tables with)."""
+        key = ("pos", batch, grid, str(device))
+        t = self._tables.get(key)
+        if t is None:
+            t = self._tables[key] = ops.rope_pos_code(batch, grid, device)
+        return t
+
     def rope_tables(self, P: Dict[str, torch.Tensor], grid, device) -> torch.Tensor:
         key = (grid, str(device))
         t = self._tables.get(key)
@@ -319,8 +327,10 @@ class EncoderEngine:
         ln1 = buf("ln1", D, BF16)
         ops.layernorm_fwd(x, P[p + "norm1.weight"], P[p + "norm1.bias"], ln1, mean1, rstd1, LN_EPS)
         qkv = buf("qkv", 3 * D, BF16)
-        ops.gemm_nt(ln1, Wc.fwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, qkv)
-        ops.rope3d_qk_(qkv, tables, grid)
+        # the projection with the rotation in its epilogue; small problems take the two-pass route
+        if not ops.gemm_nt_qkv_rope(ln1, Wc.fwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), qkv, tables, self.rope_pos(B, grid, dev), grid):
+            ops.gemm_nt(ln1, Wc.fwd(p + "qkv", P[p + "attn.qkv_proj.weight"]), ops.EPI_BF16, qkv)
+            ops.rope3d_qk_(qkv, tables, grid)
         attn = buf("attn", D, BF16)
         lse2 = torch.empty(B * H, N, dtype=F32, device=dev) if keep else scratch.setdefault(
             "lse2", torch.empty(B * H, N, dtype=F32, device=dev))

@@ -256,6 +256,44 @@ def rope3d_qk_(qkv: torch.Tensor, tables: torch.Tensor, grid: Tuple[int, int, in
     return qkv
 
 
+def rope_pos_code(batch: int, grid: Tuple[int, int, int], device) -> torch.Tensor:
+    """int32 [batch * Tp*Hp*Wp]: t | h << 10 | w << 20 of every token row (token order t, h, w; swm:225-240)."""
+    Tp, Hp, Wp = grid
+    if max(grid) >= 1024:
+        raise ValueError("rope_pos_code: grid coordinates must stay below 1024")
+    n = torch.arange(Tp * Hp * Wp, dtype=torch.int64)
+    code = (n // (Hp * Wp)) | (((n // Wp) % Hp) << 10) | ((n % Wp) << 20)
+    return code.to(torch.int32).repeat(batch).to(device)
+
+
+# VIT_AMD_FUSED_ROPE=0 makes the encoder take the two-pass route (projection GEMM, then the rotation pass): for A/B timing
+_fused_rope = os.environ.get("VIT_AMD_FUSED_ROPE", "1") != "0"
+
+
+def gemm_nt_qkv_rope(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, tables: torch.Tensor, pos_code: torch.Tensor,
+                     grid: Tuple[int, int, int]) -> bool:
+    """out[M, 3072] (bf16) = rotary(x[M, K] @ w[3072, K]^T): the QKV projection with the rotation of `rope3d_qk_` applied
+    in the GEMM's epilogue.  Returns False when the fused kernel cannot take the call (small M, or no persistent-kernel
+    ticket set left for the stream): the caller then runs gemm_nt + rope3d_qk_."""
+    _need(x, BF16, "x"); _need(w, BF16, "w"); _need(out, BF16, "out"); _need(tables, F32, "tables")
+    _need(pos_code, torch.int32, "pos_code")
+    M, K = x.shape
+    Tp, Hp, Wp = grid
+    if tuple(w.shape) != (3072, K) or tuple(out.shape) != (M, 3072) or pos_code.numel() != M:
+        raise ValueError("gemm_nt_qkv_rope: inconsistent shapes")
+    if tables.numel() != 2 * (Tp * 128 + Hp * 192 + Wp * 192):
+        raise ValueError("gemm_nt_qkv_rope: table size does not match the grid")
+    if not _fused_rope or M < 2048 or K < 192 or K % 64:
+        return False
+    lib = _lib.load()
+    rc = lib.va_gemm_nt_qkv_rope(_p(x), _p(w), M, K, _ld(x), _ld(w), _p(out), _ld(out), _p(tables), _p(pos_code), Tp, Hp, Wp,
+                                 _stream())
+    if rc == -3:          # VA_ERR_UNSUPPORTED_SHAPE: no ticket set left for this stream
+        return False
+    check(rc, "va_gemm_nt_qkv_rope")
+    return True
+
+
 def rope3d_qk_indexed_(qkv: torch.Tensor, cache, pos: torch.Tensor, n_tokens: int, transpose: bool = False):
     """General rotation of the Q and K thirds of a packed [M, 3072] bf16 buffer (swm:265-281): `cache` =
     ((cos_t, sin_t), (cos_h, sin_h), (cos_w, sin_w)) full-width f32 device tables as VideoRoPE3D.forward returns
