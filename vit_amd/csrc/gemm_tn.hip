@@ -194,14 +194,25 @@ constexpr int ROP_BYTES = RBM * 256 * 2;      // 16 KiB per operand per stage
 constexpr int RSTAGE_BYTES = 2 * ROP_BYTES;
 constexpr int RRING = 5;
 
-template <bool DO_BIAS>
+template <int N>
+VA_DEVINL void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NW = 8: waves 2 x 4, each 128(n) x 64(k).  NW = 4: waves 2 x 2, each 128 x 128 with 256 accumulator registers (one
+// wave per SIMD): a stage then costs 16 fragment reads per wave instead of 12 for twice the MFMAs, i.e. two thirds of the
+// LDS read traffic per FLOP -- the LDS pipe (transposing reads plus the direct-to-LDS writes) is what the eight-wave
+// form keeps busiest.
+template <int NW, bool DO_BIAS>
 VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
                                   int M, int N, int K, int lddy, int ldx, float* __restrict__ DW, int lddw,
                                   int m_per_slice, float* __restrict__ DBIAS, int work) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor type exists for the device target only
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 2, wk = wave & 3;
+    constexpr int THREADS = NW * 64, WK = NW / 2, TB = 256 / WK / 16, CPT = 1024 / THREADS, NBIAS = 8 / WK;
+    const int wn = wave / WK, wk = wave % WK;
 
     // Work ids are slice-major, and the workgroups that share an XCD take one contiguous run of them: the
     // ~32 workgroups resident on an XCD then sweep the SAME rows of dY and X (one M slice) for a compact
@@ -220,37 +231,53 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
     const int nk = (m_end - m_begin + RBM - 1) / RBM;            // >= 4 (host guarantees)
     const int tail_valid = (m_end - m_begin) - (nk - 1) * RBM;   // rows valid in the last stage (1..32)
 
-    // staging: 1024 chunks per operand per stage, 2 per thread: chunk q -> row q>>5, slot q&31
-    int srow[2], scol[2];
+    // staging: 1024 chunks per operand per stage, CPT per thread: chunk q -> row q>>5, slot q&31.  Sources go through
+    // buffer descriptors based at the slice's first row and the tile's first column and sized to the rows that exist:
+    // lanes whose row lies past M fetch nothing (their LDS bytes are blanked after the last stage has landed).  (The
+    // buffer form also keeps the compiler's LDS wait counts exact: behind a flat-family load into LDS it waits for every outstanding
+    // LDS read before the next use of any.)  The stage's row offset is part of the VECTOR offset: the range check
+    // does not see the scalar offset.
+    const int64_t ybytes = (int64_t)(M - m_begin) * lddy * 2 - (int64_t)n0 * 2;
+    const int64_t xbytes = (int64_t)(M - m_begin) * ldx * 2 - (int64_t)k0 * 2;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(DY + (size_t)m_begin * lddy + n0), (short)0, (int)(ybytes < 0x7fffffff ? ybytes : 0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(X + (size_t)m_begin * ldx + k0), (short)0, (int)(xbytes < 0x7fffffff ? xbytes : 0x7fffffff), 0x00020000);
+    int yvo[CPT], xvo[CPT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = i * 512 + tid;
-        srow[i] = q >> 5;
-        scol[i] = ((q & 31) ^ ((srow[i] & 3) << 2) ^ (((srow[i] >> 3) & 1) << 1)) * 8;
+    for (int i = 0; i < CPT; ++i) {
+        const int q = i * THREADS + tid, row = q >> 5;
+        const int col = ((q & 31) ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 1)) * 8;
+        yvo[i] = (row * lddy + col) * 2;
+        xvo[i] = (row * ldx + col) * 2;
     }
-    auto stage = [&](int kt, int slot) {
+    // load j (0 .. 2*CPT-1) of a stage: chunk j>>1 of dY (j even) or of X (j odd)
+    auto stage_one = [&](int kt, int slot, int j) {
         char* yb = smem + slot * RSTAGE_BYTES;
-        char* xb = yb + ROP_BYTES;
-        const int mb = m_begin + kt * RBM;
+        const int i = j >> 1;
+        if ((j & 1) == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(yb + (i * THREADS + wave * 64) * 16), 16,
+                                                     yvo[i] + kt * RBM * lddy * 2, 0, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(yb + ROP_BYTES + (i * THREADS + wave * 64) * 16), 16,
+                                                     xvo[i] + kt * RBM * ldx * 2, 0, 0, 0);
+    };
+    auto stage = [&](int kt, int slot) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int m = mb + srow[i];
-            m = m < M ? m : M - 1;
-            glds16(DY + (size_t)m * lddy + n0 + scol[i], yb + (i * 512 + wave * 64) * 16);
-            glds16(X + (size_t)m * ldx + k0 + scol[i], xb + (i * 512 + wave * 64) * 16);
-        }
+        for (int j = 0; j < 2 * CPT; ++j) stage_one(kt, slot, j);
     };
 
     // D[n][k]: dY^T is the A operand, X the B operand: lane holds rows n = 4*(lane>>4) + j, column k = lane & 15
-    f32x4_t acc[8][4];
+    f32x4_t acc[8][TB];
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TB; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     constexpr bool do_bias = DO_BIAS;
-    f32x4_t bacc[2];                // wave (wn, wk) sums the columns of n-blocks a = 2*wk, 2*wk + 1
-    bacc[0] = bacc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t bacc[NBIAS];            // wave (wn, wk) sums the columns of n-blocks a = NBIAS*wk .. NBIAS*wk + NBIAS-1
+#pragma unroll
+    for (int jj = 0; jj < NBIAS; ++jj) bacc[jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, (u32x4_t){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
     // A 16x16x32 operand fragment: lane l holds 8 consecutive m (k-group l>>4) of column l & 15.  Its 16-lane group
@@ -262,60 +289,83 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
         const int chunk = ((colbase + 4 * p) >> 3) ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 1);
         return row * 512 + (chunk << 4) + (p & 1) * 8;
     };
-    int yoff[8], xoff[4];
+    int yoff[8], xoff[TB];
 #pragma unroll
     for (int a = 0; a < 8; ++a) yoff[a] = tr_off(wn * 128 + a * 16);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) xoff[b] = ROP_BYTES + tr_off(wk * 64 + b * 16);
+    for (int b = 0; b < TB; ++b) xoff[b] = ROP_BYTES + tr_off(wk * (TB * 16) + b * 16);
 
     // fragment of the stage in `slot`
     auto frag = [&](int slot, int off) {
         const char* ptr = smem + slot * RSTAGE_BYTES + off;
         return join_tr(lds_read_tr16(ptr), lds_read_tr16(ptr + 4 * 512));
     };
-    bf16x8_t fa[8], fb[4], fbn[4];
-    int ymine[2];
+    bf16x8_t fa[8], fb[TB], fbn[TB];
+    int ymine[NBIAS];
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) ymine[jj] = tr_off(wn * 128 + (2 * wk + jj) * 16);
+    for (int jj = 0; jj < NBIAS; ++jj) ymine[jj] = tr_off(wn * 128 + (NBIAS * wk + jj) * 16);
 
     // zero rows [valid, 32) of both operand tiles of a slot (ragged end of M)
     auto zero_tail = [&](int slot, int valid) {
         char* base = smem + slot * RSTAGE_BYTES;
-        for (int c = tid; c < 2 * RBM * 32; c += 512) {
+        for (int c = tid; c < 2 * RBM * 32; c += THREADS) {
             const int r = (c >> 5) & (RBM - 1);
             if (r >= valid) *(u32x4_t*)(base + c * 16) = (u32x4_t){0u, 0u, 0u, 0u};
         }
     };
 
-    // one stage: 32 MFMAs; after the four MFMAs of n-block a the next stage's dY fragment a replaces the retired
-    // one and (a < 4) X fragment a of the next stage is read into the spare set
-    auto kstep = [&](auto prefetch, int cur_slot, int nslot, bool bias_now) {
+    // one stage: 8 * TB MFMAs against the X fragments in `fc`; after the TB MFMAs of n-block a the next stage's dY
+    // fragment a replaces the retired one, and during the first four n-blocks the next stage's X fragments are read into
+    // the other set `fx` -- the next stage's first MFMAs need all of them, so they go first; the two sets swap roles from
+    // stage to stage (no register copies: with one wave per SIMD nothing would cover them)
+    // Four waves: the 256 accumulators are pinned to the accumulation registers by issuing the MFMAs as volatile asm
+    // with an accumulation-register operand (left to the register allocator such a set is shuffled between the two
+    // register files inside the loop); volatile statements keep their order and the empty memory-clobbering statements
+    // pin the LDS reads and the stage's global loads (`load_kt` >= 0: one per n-block) between them.
+    auto mf = [](f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {
+        if constexpr (NW == 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+        else c = mfma16(a, b, c);
+    };
+    auto kstep = [&](auto prefetch, bf16x8_t (&fc)[TB], bf16x8_t (&fx)[TB], int cur_slot, int nslot, bool bias_now,
+                     int load_kt, int load_slot) {
         constexpr bool PREFETCH = decltype(prefetch)::value;
         if (DO_BIAS && bias_now) {
             // uniform branch: this workgroup's share of the M stages.  The wave's two n-blocks are a run-time choice
             // (by wave index), so their fragments are read again from the stage's slot rather than selected out of
             // the register set with 24 conditional moves.
-            const bf16x8_t m0 = frag(cur_slot, ymine[0]), m1 = frag(cur_slot, ymine[1]);
-            bacc[0] = mfma16(m0, ones, bacc[0]);
-            bacc[1] = mfma16(m1, ones, bacc[1]);
+#pragma unroll
+            for (int jj = 0; jj < NBIAS; ++jj) {
+                const bf16x8_t mine = frag(cur_slot, ymine[jj]);
+                // four waves: every accumulation register belongs to the pinned tile accumulators; a compiler-issued
+                // MFMA here would borrow some of them with copies whose hazards against the asm MFMAs it cannot see
+                // (the s_nop: the compiler materialises the all-ones operand with moves right in front of the statement
+                // and, not knowing it for an MFMA, leaves out the wait states between a vector write and an MFMA read)
+                if constexpr (NW == 4)
+                    asm volatile("s_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(bacc[jj]) : "v"(mine), "v"(ones));
+                else bacc[jj] = mfma16(mine, ones, bacc[jj]);
+            }
         }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+            for (int b = 0; b < TB; ++b) mf(acc[a][b], fa[a], fc[b]);
+            if (NW == 4) asm volatile("" ::: "memory");
+            if (NW == 4 && load_kt >= 0) stage_one(load_kt, load_slot, a);
             if (PREFETCH) {
                 fa[a] = frag(nslot, yoff[a]);
-                if (a < 4) fbn[a] = frag(nslot, xoff[a]);
+                if (a < 4) {
+#pragma unroll
+                    for (int h = 0; h < TB / 4; ++h) fx[a * (TB / 4) + h] = frag(nslot, xoff[a * (TB / 4) + h]);
+                }
             }
+            if (NW == 4) asm volatile("" ::: "memory");
         }
-        if (PREFETCH) {
+        if (PREFETCH && NW == 8) {
 #define VA_GRP(n_reads)                                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       \
+    __builtin_amdgcn_sched_group_barrier(0x008, TB, 0);      \
     __builtin_amdgcn_sched_group_barrier(0x100, n_reads, 0);
             VA_GRP(4) VA_GRP(4) VA_GRP(4) VA_GRP(4) VA_GRP(2) VA_GRP(2) VA_GRP(2) VA_GRP(2)
 #undef VA_GRP
-#pragma unroll
-            for (int b = 0; b < 4; ++b) fb[b] = fbn[b];
         }
     };
     // the bias column sums are spread over the k-tile workgroups of an output row: each takes every
@@ -330,34 +380,48 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
     stage(1, 1);
     stage(2, 2);
     stage(3, 3);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    wait_vm<6 * CPT>();
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // (X fragments first: inside the loop they are also the earlier reads, and the compiler's wait counts at the loop head
+    // are the stricter of the two paths into it)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) fb[b] = frag(0, xoff[b]);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int a = 0; a < 8; ++a) fa[a] = frag(0, yoff[a]);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) fb[b] = frag(0, xoff[b]);
 
     int slot = 0;
     int kt = 0;
-    for (; kt + 4 < nk; ++kt) {           // stages with three successors in flight
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    auto ring_prev = [&](int sl) { return sl == 0 ? RRING - 1 : sl - 1; };
+    auto mid = [&](bf16x8_t (&fc)[TB], bf16x8_t (&fx)[TB]) {       // a stage with three successors in flight
+        wait_vm<4 * CPT>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        stage(kt + 4, slot == 0 ? RRING - 1 : slot - 1);
-        kstep(Yes{}, slot, advance(slot), bias_stage(kt));
+        if (NW == 8) stage(kt + 4, ring_prev(slot));
+        kstep(Yes{}, fc, fx, slot, advance(slot), bias_stage(kt), kt + 4, ring_prev(slot));
         slot = advance(slot);
+        ++kt;
+    };
+    while (kt + 5 < nk) {
+        mid(fb, fbn);
+        mid(fbn, fb);
+    }
+    if (kt + 4 < nk) {                    // an odd one left over: one copy per kernel puts the sets back in step
+        mid(fb, fbn);
+#pragma unroll
+        for (int b2 = 0; b2 < TB; ++b2) fb[b2] = fbn[b2];
     }
     // tail: stages nk-4 .. nk-1
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    wait_vm<4 * CPT>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    kstep(Yes{}, slot, advance(slot), bias_stage(kt));
+    kstep(Yes{}, fb, fbn, slot, advance(slot), bias_stage(kt), -1, 0);
     slot = advance(slot); ++kt;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    wait_vm<2 * CPT>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    kstep(Yes{}, slot, advance(slot), bias_stage(kt));
+    kstep(Yes{}, fbn, fb, slot, advance(slot), bias_stage(kt), -1, 0);
     slot = advance(slot); ++kt;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -366,31 +430,37 @@ VA_DEVINL void gemm_tn_ring_body(const bf16_t* __restrict__ DY, const bf16_t* __
         zero_tail(advance(slot), tail_valid);
         __syncthreads();
     }
-    kstep(Yes{}, slot, advance(slot), bias_stage(kt));
+    kstep(Yes{}, fb, fbn, slot, advance(slot), bias_stage(kt), -1, 0);
     slot = advance(slot); ++kt;
-    kstep(No{}, slot, 0, bias_stage(kt));
+    kstep(No{}, fbn, fbn, slot, 0, bias_stage(kt), -1, 0);
 
     // one accumulator register across the wave: four 64-byte row segments of dW
     const int rg = lane >> 4, col = lane & 15;
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            float* base = DW + (size_t)(n0 + wn * 128 + a * 16 + 4 * rg) * lddw + k0 + wk * 64 + b * 16 + col;
+        for (int b = 0; b < TB; ++b) {
+            float* base = DW + (size_t)(n0 + wn * 128 + a * 16 + 4 * rg) * lddw + k0 + wk * (TB * 16) + b * 16 + col;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(base + (size_t)j * lddw, acc[a][b][j]);
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[a][b][j];
+                // read out of the accumulation file at the point of use: hoisted, the 256 copies would spill
+                if constexpr (NW == 4) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[a][b][j]));
+                unsafeAtomicAdd(base + (size_t)j * lddw, v);
+            }
         }
     if (do_bias && col == 0) {   // every column of bacc holds the same sums: lane column 0 publishes them
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < NBIAS; ++jj)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                unsafeAtomicAdd(DBIAS + n0 + wn * 128 + (2 * wk + jj) * 16 + 4 * rg + j, bacc[jj][j]);
+                unsafeAtomicAdd(DBIAS + n0 + wn * 128 + (NBIAS * wk + jj) * 16 + 4 * rg + j, bacc[jj][j]);
     }
+#endif
 }
 
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
+template <int NW, bool HAS_BIAS>
+__global__ __launch_bounds__(NW * 64) void gemm_tn_ring_kernel(const bf16_t* __restrict__ DY, const bf16_t* __restrict__ X,
                                                            int M, int N, int K, int lddy, int ldx,
                                                            float* __restrict__ DW, int lddw, int m_per_slice,
                                                            float* __restrict__ DBIAS) {
@@ -398,7 +468,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16_t* __restr
     const int tiles_k = K / 256;
     const int tiles = (N / 256) * tiles_k;
     (void)tiles;
-    gemm_tn_ring_body<HAS_BIAS>(DY, X, M, N, K, lddy, ldx, DW, lddw, m_per_slice, DBIAS, work);
+    gemm_tn_ring_body<NW, HAS_BIAS>(DY, X, M, N, K, lddy, ldx, DW, lddw, m_per_slice, DBIAS, work);
 }
 
 }  // namespace
@@ -432,28 +502,33 @@ extern "C" int va_gemm_tn_accum(const void* dy, const void* x, int64_t M, int64_
         const int64_t m_per = per * RBM;
         const int slices = (int)((M + m_per - 1) / m_per);
         const int64_t last = M - (int64_t)(slices - 1) * m_per;   // rows of the last slice
-        if (last >= 4 * RBM - (RBM - 1) && (last + RBM - 1) / RBM >= 4) {
-            static bool ring_attr[2][64] = {};
+        // (a slice's rows must lie within one buffer descriptor's 2 GiB)
+        const bool fits = (m_per + RBM) * (lddy > ldx ? lddy : ldx) * 2 < 0x7fffffffll;
+        if (fits && last >= 4 * RBM - (RBM - 1) && (last + RBM - 1) / RBM >= 4) {
+            // four waves with 128 x 128 each unless VA_GEMM_TN_WAVES=8 asks for the eight-wave form (A/B timing)
+            static const bool eight = [] {
+                const char* e = getenv("VA_GEMM_TN_WAVES");
+                return e && atoi(e) == 8;
+            }();
+            static bool ring_attr[4][64] = {};
             int dev = 0;
             (void)hipGetDevice(&dev);
-            const int hb = dbias != nullptr;
-            const void* kern = hb ? (const void*)gemm_tn_ring_kernel<true> : (const void*)gemm_tn_ring_kernel<false>;
-            if (dev >= 0 && dev < 64 && !ring_attr[hb][dev]) {
-                if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, RRING * RSTAGE_BYTES) !=
+            const int hb = dbias != nullptr, which = 2 * (int)eight + hb;
+            using Kern = void (*)(const bf16_t*, const bf16_t*, int, int, int, int, int, float*, int, int, float*);
+            const Kern kerns[4] = {gemm_tn_ring_kernel<4, false>, gemm_tn_ring_kernel<4, true>, gemm_tn_ring_kernel<8, false>,
+                                   gemm_tn_ring_kernel<8, true>};
+            const Kern kern = kerns[which];
+            if (dev >= 0 && dev < 64 && !ring_attr[which][dev]) {
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RRING * RSTAGE_BYTES) !=
                     hipSuccess) {
                     va_set_error("va_gemm_tn_accum: cannot reserve %d bytes of LDS", RRING * RSTAGE_BYTES);
                     return VA_ERR_LAUNCH;
                 }
-                ring_attr[hb][dev] = true;
+                ring_attr[which][dev] = true;
             }
-            if (hb)
-                hipLaunchKernelGGL(gemm_tn_ring_kernel<true>, dim3(rtiles * slices), dim3(512), RRING * RSTAGE_BYTES,
-                                   stream, (const bf16_t*)dy, (const bf16_t*)x, (int)M, (int)N, (int)K, (int)lddy,
-                                   (int)ldx, dw, (int)lddw, (int)m_per, dbias);
-            else
-                hipLaunchKernelGGL(gemm_tn_ring_kernel<false>, dim3(rtiles * slices), dim3(512), RRING * RSTAGE_BYTES,
-                                   stream, (const bf16_t*)dy, (const bf16_t*)x, (int)M, (int)N, (int)K, (int)lddy,
-                                   (int)ldx, dw, (int)lddw, (int)m_per, dbias);
+            hipLaunchKernelGGL(kern, dim3(rtiles * slices), dim3(eight ? 512 : 256), RRING * RSTAGE_BYTES, stream,
+                               (const bf16_t*)dy, (const bf16_t*)x, (int)M, (int)N, (int)K, (int)lddy, (int)ldx, dw, (int)lddw,
+                               (int)m_per, dbias);
             VA_CHECK_LAUNCH("va_gemm_tn_accum");
             return VA_OK;
         }
