@@ -32,6 +32,18 @@ VA_DEVINL int swz(int row) {
     return ((row & 3) << 2) | ((row >> 2) & 3);                          // 16 chunks per 256-byte row
 }
 
+// One BYTES-wide piece per lane, global -> LDS, through a buffer descriptor over [base, base + span) (base wave-uniform,
+// `voff` the lane's byte offset).  The buffer form rather than the flat-family global_load_lds: behind the latter the
+// compiler drains every outstanding LDS read before the next use of any; with this one its LDS wait counts are exact.
+template <int BYTES>
+VA_DEVINL void buf_to_lds(const void* base, int span, int voff, void* lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the descriptor type exists for the device target only
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, span, 0x00020000);
+    if constexpr (BYTES == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_wave_base, 16, voff, 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_wave_base, 4, voff, 0, 0, 0);
+#endif
+}
+
 // Stage a [ROWS x HD] bf16 tile: rows row0..row0+ROWS-1 (clamped to n_rows-1) of `src` (row stride ld).
 template <int HD, int ROWS = TILE_ROWS>
 VA_DEVINL void stage_tile(const bf16_t* src, int64_t ld, int row0, int n_rows, char* dst, int tid,
@@ -45,7 +57,8 @@ VA_DEVINL void stage_tile(const bf16_t* src, int64_t ld, int row0, int n_rows, c
         const int c = (q % CPR) ^ swz<HD>(row);
         int g = row0 + row;
         g = g < n_rows ? g : n_rows - 1;
-        glds16(src + (int64_t)g * ld + c * 8, dst + (i * 256 + wave * 64) * 16);
+        buf_to_lds<16>(src + (int64_t)row0 * ld, (int)((TILE_ROWS - 1) * ld * 2 + HD * 2), (int)(((g - row0) * ld + c * 8) * 2),
+                       dst + (i * 256 + wave * 64) * 16);
     }
 }
 
@@ -70,9 +83,11 @@ VA_DEVINL void stage_tile_at(const TileSrc<HD>& ts, const bf16_t* src, int64_t l
         stage_tile<HD>(src, ld, row0, n_rows, dst, tid, wave);
         return;
     }
-    const char* base = (const char*)(src + (int64_t)row0 * ld);
+    // one descriptor over the tile's rows (scalar registers; wave-uniform base)
 #pragma unroll
-    for (int i = 0; i < TileSrc<HD>::PER_THREAD; ++i) glds16(base + ts.off[i], dst + (i * 256 + wave * 64) * 16);
+    for (int i = 0; i < TileSrc<HD>::PER_THREAD; ++i)
+        buf_to_lds<16>(src + (int64_t)row0 * ld, (int)((TILE_ROWS - 1) * ld * 2 + HD * 2), (int)ts.off[i],
+                       dst + (i * 256 + wave * 64) * 16);
 }
 
 // Row-read fragment (MFMA operand with the tile's rows as the M/N index): lane (r = lane&31, h = lane>>5)
@@ -688,12 +703,12 @@ __global__ __launch_bounds__(256, HD <= 64 ? 2 : 1) void attn_bwd_dkv_kernel(con
         if (wave == 0) {   // 64 records of 16 bytes; rows past N are clamped here and masked in the compute
             int r = tile * TILE_ROWS + lane;
             r = r < N ? r : N - 1;
-            glds16(aux_b + r, nb + 2 * TB);
+            buf_to_lds<16>(aux_b, N * 16, r * 16, nb + 2 * TB);
         }
         if (DROP && wave == 1) {   // the same queries' -delta as plain f32, read back per register in the mask step
             int r = tile * TILE_ROWS + lane;
             r = r < N ? r : N - 1;
-            glds4(NEG_DELTA + (int64_t)bh * N + r, nb + 2 * TB + TILE_ROWS * 16);
+            buf_to_lds<4>(NEG_DELTA + (int64_t)bh * N, N * 4, r * 4, nb + 2 * TB + TILE_ROWS * 16);
         }
     };
     stage(0, 0);
@@ -938,7 +953,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const bf16_t* __
         char* nb = smem + slot * STAGE;
         stage_tile_at<HD, false>(ts_q, Qb, ld, tile * TILE_ROWS, N, nb, tid, wave);
         stage_tile_at<HD, false>(ts_do, DOb, ldo, tile * TILE_ROWS, N, nb + TB, tid, wave);
-        glds16(aux_b + tile * TILE_ROWS + lane, nb + 2 * TB);      // 64 records of 16 bytes (every wave: the same 1 KiB)
+        buf_to_lds<16>(aux_b + tile * TILE_ROWS, TILE_ROWS * 16, lane * 16, nb + 2 * TB);   // 64 records of 16 bytes (every wave: the same 1 KiB)
     };
 
     f32x16_t s[2], dp[2];                    // two sets, by key sub-block: one is consumed while the other is produced
@@ -976,9 +991,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(const bf16_t* __
     // landed everywhere, and nobody reads tile t any more (its slot is refilled from the next step on).
 #define LD_TILE(i)                                                                                                       \
     DKV_PIN;                                                                                                             \
-    if constexpr ((i) < 2) glds16((const char*)(Qb + ld_row0 * ld) + ts_q.off[(i) & 1], ld_dst + (((i) & 1) * 256 + wave * 64) * 16);         \
-    else if constexpr ((i) < 4) glds16((const char*)(DOb + ld_row0 * ldo) + ts_do.off[(i) & 1], ld_dst + TB + (((i) & 1) * 256 + wave * 64) * 16); \
-    else glds16(aux_b + ld_row0 + lane, ld_dst + 2 * TB);     /* every wave: same 1 KiB, no branch in the step */        \
+    if constexpr ((i) < 2) buf_to_lds<16>(Qb + ld_row0 * ld, (int)((TILE_ROWS - 1) * ld * 2 + HD * 2), (int)ts_q.off[(i) & 1], ld_dst + (((i) & 1) * 256 + wave * 64) * 16); \
+    else if constexpr ((i) < 4) buf_to_lds<16>(DOb + ld_row0 * ldo, (int)((TILE_ROWS - 1) * ldo * 2 + HD * 2), (int)ts_do.off[(i) & 1], ld_dst + TB + (((i) & 1) * 256 + wave * 64) * 16); \
+    else buf_to_lds<16>(aux_b + ld_row0, TILE_ROWS * 16, lane * 16, ld_dst + 2 * TB);     /* every wave: same 1 KiB, no branch in the step */        \
     DKV_PIN
 #define LD_STEP()                                   \
     LD_TILE(2 * QB + KB);                           \
