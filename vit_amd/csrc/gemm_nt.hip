@@ -1242,14 +1242,17 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
     VA_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) % 16 == 0, "va_gemm_nt: operands must be 16-byte aligned");
     VA_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "va_gemm_nt: problem too large");
     if (tile == 0) {
-        // Large problems: the four-wave persistent kernel for the plain 2-byte and the f32 outputs.  With one wave
-        // per SIMD nothing overlaps an epilogue's transcendental math, so the GELU epilogues stay on the eight-wave
-        // ring, whose two waves per SIMD cover each other's stalls.
+        // Large problems: the four-wave persistent kernel for the plain 2-byte and the f32 outputs and for the forward
+        // GELU epilogues (with one wave per SIMD nothing overlaps their transcendental math, but its main loop and
+        // row-contiguous stores still win: fc1 + bias + GELU 0.576 against 0.597 ms, GELU only 0.537 against 0.566 at
+        // M = 65536).  The GELU-derivative epilogue (a load per element on top of the math) measures equal on both
+        // and stays on the eight-wave ring, as do the dropout epilogues (the four-wave kernel has none).
         // ... and only when the 256-wide tiles fill most of the chip: a problem with few of them (small batches)
         // spreads over four times as many workgroups with the 128-wide tile.
         const int64_t tiles256 = ((M + 255) / 256) * (N / 256);
         const bool big = N % 256 == 0 && M >= 2048 && K >= 128 && tiles256 >= 150;
-        const bool quad = epilogue == VA_EPI_BF16 || (epilogue == VA_EPI_F32 && drop_thresh16 == 0);
+        const bool quad = epilogue == VA_EPI_BF16 ||
+                          ((epilogue == VA_EPI_F32 || epilogue == VA_EPI_BIAS_GELU || epilogue == VA_EPI_GELU_ONLY) && drop_thresh16 == 0);
         tile = !big ? 128 : quad ? 4256 : 256;
     }
     VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || tile == 4256) && N % 256 == 0 && K >= 128),
