@@ -35,6 +35,10 @@ typedef struct ihipStream_t* va_stream_t; /* == hipStream_t */
 #define VA_EPI_GELU_BWD 3  /* out(bf16) = acc * gelu_erf'(aux(bf16))                      */
 #define VA_EPI_GELU_ONLY 4 /* out(bf16) = gelu_erf(acc + bias): the forward of a pass that keeps nothing for a
                               backward (half the output bytes of VA_EPI_BIAS_GELU) */
+#define VA_EPI_BIAS_GELU_GRAD 5 /* out(bf16) = gelu_erf'(acc + bias) ; out2(bf16) = gelu_erf(acc + bias): the forward that
+                                   keeps the activation's derivative instead of the pre-activation (same bytes), so that
+                                   the backward epilogue is a multiplication (VA_EPI_MUL_AUX) with no transcendental math */
+#define VA_EPI_MUL_AUX 6        /* out(bf16) = acc * aux(bf16)                                   */
 
 int va_version(void);
 const char* va_last_error(void);
@@ -53,7 +57,9 @@ int va_gemm_nt(const void* x, const void* w, int64_t M, int64_t N, int64_t K, in
  * with the decisions va_dropout(key, p) makes over the contiguous [M,N] output (ldc == N, M*N < 2^32):
  *   VA_EPI_BIAS_GELU: out2 = drop(gelu(acc + bias));  VA_EPI_F32: out = drop(acc + bias) + resid;
  *   VA_EPI_GELU_ONLY: out = drop(gelu(acc + bias));
- *   VA_EPI_GELU_BWD:  out = drop(acc * gelu'(aux)).   p == 0 is va_gemm_nt.  Not with tile >= 4256. */
+ *   VA_EPI_GELU_BWD:  out = drop(acc * gelu'(aux));  VA_EPI_MUL_AUX: out = drop(acc * aux);
+ *   VA_EPI_BIAS_GELU_GRAD: out2 = drop(gelu(acc + bias)), out = gelu'(acc + bias) untouched.
+ *   p == 0 is va_gemm_nt.  Not with tile >= 4256. */
 int va_gemm_nt_dropout(const void* x, const void* w, int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
                        int epilogue, void* out, void* out2, const float* bias, const float* resid, const void* aux,
                        int64_t ldc, int tile, uint32_t key, float p, va_stream_t stream);

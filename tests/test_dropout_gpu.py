@@ -117,6 +117,17 @@ def test_gemm_epilogue_dropout(ops, dev, M, tile):
     ops.gemm_nt(x, w, ops.EPI_GELU_BWD, d1, aux=pre0, tile=tile, drop_key=key, drop_p=p)
     assert torch.equal(d1 == 0, (mask == 0) | (d0 == 0))
     assert (d1.float() - d0.float() * mask).abs().max().item() <= 2 ** -7 * (d0.float().abs() * mask).max().item()
+    # the derivative-keeping forward and the multiply epilogue: the same decisions, the derivative output untouched
+    dg0, a0 = torch.empty_like(pre0), torch.empty_like(act0)
+    ops.gemm_nt(x, w, ops.EPI_BIAS_GELU_GRAD, dg0, out2=a0, bias=bias, tile=tile)
+    dg1, a1 = torch.empty_like(pre0), torch.empty_like(act0)
+    ops.gemm_nt(x, w, ops.EPI_BIAS_GELU_GRAD, dg1, out2=a1, bias=bias, tile=tile, drop_key=key, drop_p=p)
+    assert torch.equal(dg1, dg0) and torch.equal(a0, act0) and torch.equal(a1, act1)
+    m0, m1 = torch.empty_like(d0), torch.empty_like(d0)
+    ops.gemm_nt(x, w, ops.EPI_MUL_AUX, m0, aux=dg0, tile=tile)
+    ops.gemm_nt(x, w, ops.EPI_MUL_AUX, m1, aux=dg0, tile=tile, drop_key=key, drop_p=p)
+    assert torch.equal(m1 == 0, (mask == 0) | (m0 == 0))
+    assert (m1.float() - m0.float() * mask).abs().max().item() <= 2 ** -7 * (m0.float().abs() * mask).max().item()
     # refusals: no dropout site in the plain epilogue, strided output, the four-wave kernel
     with pytest.raises(Exception):
         ops.gemm_nt(x, w, ops.EPI_BF16, d0, drop_key=key, drop_p=p)

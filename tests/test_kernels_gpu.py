@@ -146,6 +146,20 @@ def test_gemm_nt_epilogues(ops, dev, tile, M):
     p = pre.float().requires_grad_(True)
     torch.nn.functional.gelu(p).backward(acc)
     assert rel_err(g, p.grad) < 5e-3
+    # the forward that keeps GELU'(pre-activation) instead of the pre-activation, and the multiply epilogue that uses it:
+    # the activation is the very same bits, the derivative is the f32 pre-activation's (not the rounded one's)
+    dact = torch.empty(M, N, dtype=BF16, device=dev)
+    act2 = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_BIAS_GELU_GRAD, dact, out2=act2, bias=bias, tile=tile)
+    assert torch.equal(act2, act)
+    h = (acc + bias).double()
+    dref = 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0))) + h * torch.exp(-0.5 * h * h) / math.sqrt(2.0 * math.pi)
+    assert (dact.double() - dref).abs().max().item() < 6e-3          # bf16 rounding of values up to ~1.13
+    assert rel_err(dact, dref.float()) < 3e-3
+    g2 = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm_nt(x, w, ops.EPI_MUL_AUX, g2, aux=dact, tile=tile)
+    assert rel_err(g2, acc * dact.float()) < 3e-3
+    assert rel_err(g2, acc * dref.float()) < 5e-3
 
 
 def test_gemm_nt_rejects_bad_shapes(ops, dev):

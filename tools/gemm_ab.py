@@ -14,9 +14,9 @@ from vit_amd import _lib  # noqa: E402
 dev = torch.device("cuda:0")
 BF16, F32 = torch.bfloat16, torch.float32
 M, D = int(os.environ.get("AB_M", "65536")), 1024
-EPI = {"bf16": 0, "bias+gelu": 1, "f32+bias+resid": 2, "f32+bias": 2, "xgelu'": 3, "gelu-only": 4}
+EPI = {"bf16": 0, "bias+gelu": 1, "f32+bias+resid": 2, "f32+bias": 2, "xgelu'": 3, "gelu-only": 4, "bias+gelu+grad": 5, "xaux": 6}
 CASES = [("qkv", 3 * D, D, "bf16"), ("out", D, D, "f32+bias+resid"), ("fc1", 4 * D, D, "bias+gelu"), ("fc1", 4 * D, D, "gelu-only"),
-         ("fc2", D, 4 * D, "f32+bias+resid"), ("dact", 4 * D, D, "xgelu'"), ("dln2", D, 4 * D, "bf16"), ("dattn", D, D, "bf16"),
+         ("fc2", D, 4 * D, "f32+bias+resid"), ("dact", 4 * D, D, "xgelu'"), ("fc1", 4 * D, D, "bias+gelu+grad"), ("dact", 4 * D, D, "xaux"), ("dln2", D, 4 * D, "bf16"), ("dattn", D, D, "bf16"),
          ("dln1", D, 3 * D, "bf16"), ("out", D, D, "f32+bias"), ("out", D, D, "bf16")]
 if os.environ.get("AB_CASES"):
     CASES = [c for c in CASES if any(k in c[0] + ":" + c[3] for k in os.environ["AB_CASES"].split(","))]
@@ -40,7 +40,7 @@ for name, N, K, epi in CASES:
     w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(BF16)
     bias = torch.randn(N, device=dev, generator=g) if "bias" in epi or epi == "gelu-only" else None
     resid = torch.randn(M, N, device=dev, generator=g) if "resid" in epi else None
-    aux = torch.randn(M, N, device=dev, generator=g).to(BF16) if epi == "xgelu'" else None
+    aux = torch.randn(M, N, device=dev, generator=g).to(BF16) if epi in ("xgelu'", "xaux") else None
     odt = F32 if epi.startswith("f32") else BF16
     outs, times = [], [[] for _ in libs]
 
@@ -50,7 +50,7 @@ for name, N, K, epi in CASES:
                             None if resid is None else resid.data_ptr(), None if aux is None else aux.data_ptr(), N, tile, st)
         assert rc == 0, lib.va_last_error()
 
-    bufs = [(torch.zeros(M, N, dtype=odt, device=dev), torch.zeros(M, N, dtype=BF16, device=dev) if epi == "bias+gelu" else None)
+    bufs = [(torch.zeros(M, N, dtype=odt, device=dev), torch.zeros(M, N, dtype=BF16, device=dev) if epi in ("bias+gelu", "bias+gelu+grad") else None)
             for _ in libs]
     for rnd in range(3):
         for i, (_, lib) in enumerate(libs):

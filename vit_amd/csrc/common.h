@@ -104,6 +104,15 @@ VA_DEVINL float gelu_erf_grad(float x) {
     return fmaf(x * 0.39894228040143268f, g, cdf);
 }
 
+// Both at once (the forward epilogue that keeps the derivative, not the pre-activation, for the backward pass)
+VA_DEVINL void gelu_erf_both(float x, float& gelu, float& grad) {
+    float h, g;
+    gelu_parts(x, h, g);
+    gelu = fmaf(-fabsf(x), h, fmaxf(x, 0.f));
+    const float cdf = x >= 0.f ? 1.0f - h : h;
+    grad = fmaf(x * 0.39894228040143268f, g, cdf);
+}
+
 // Map a launch-order block id onto a work id so that the blocks that share an XCD (ids equal mod 8)
 // receive one contiguous run of work ids: neighbouring tiles then reuse each other's operand panels
 // in that XCD's L2.  Bijective for every block count.

@@ -35,10 +35,10 @@ namespace {
 
 struct EpiArgs {
     void* out;            // bf16 or f32 [M, ldc]
-    void* out2;           // bf16 [M, ldc]: GELU output (VA_EPI_BIAS_GELU)
+    void* out2;           // bf16 [M, ldc]: GELU output (VA_EPI_BIAS_GELU, VA_EPI_BIAS_GELU_GRAD)
     const float* bias;    // [N] or null
     const float* resid;   // f32 [M, ldc] or null (VA_EPI_F32)
-    const bf16_t* aux;    // bf16 [M, ldc]: saved pre-activation (VA_EPI_GELU_BWD)
+    const bf16_t* aux;    // bf16 [M, ldc]: saved pre-activation (VA_EPI_GELU_BWD) or factor (VA_EPI_MUL_AUX)
     int ldc;
     // Fused dropout (drop_thi != 0): applied to the GELU output (BIAS_GELU: out2), to acc + bias before the residual
     // (F32), to the product with the GELU derivative (GELU_BWD).  Decisions are those of va_dropout over a contiguous
@@ -52,6 +52,9 @@ struct EpiArgs {
     int rope_tp, rope_hp, rope_wp;
 };
 constexpr int EPI_QKV_ROPE = 100;      // internal epilogue code: reached through va_gemm_nt_qkv_rope only
+
+constexpr bool epi_reads_aux(int epi) { return epi == VA_EPI_GELU_BWD || epi == VA_EPI_MUL_AUX; }
+constexpr bool epi_two_outputs(int epi) { return epi == VA_EPI_BIAS_GELU || epi == VA_EPI_BIAS_GELU_GRAD; }
 
 // keep-or-zero and rescale of `cnt` (even) consecutive elements starting at element index e0 (even)
 template <int CNT>
@@ -79,7 +82,7 @@ VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M
             const int nb = n_wave + a * 16 + (lane >> 4) * 4;
             const size_t o = (size_t)m * ldc + nb;
             float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            if (EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
+            if (!epi_reads_aux(EPI) && ep.bias != nullptr) {
                 const f32x4_t bv = *(const f32x4_t*)(ep.bias + nb);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += bv[j];
@@ -91,6 +94,15 @@ VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M
                 u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *(u32x2_t*)((bf16_t*)ep.out + o) = pk;
                 float gl[4] = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+                if (ep.drop_thi) drop_run<4>(gl, (uint32_t)o, ep);
+                u32x2_t gk = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3])};
+                *(u32x2_t*)((bf16_t*)ep.out2 + o) = gk;
+            } else if (EPI == VA_EPI_BIAS_GELU_GRAD) {
+                float gl[4], gd[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gelu_erf_both(v[j], gl[j], gd[j]);
+                u32x2_t dk = {pack_bf16x2(gd[0], gd[1]), pack_bf16x2(gd[2], gd[3])};
+                *(u32x2_t*)((bf16_t*)ep.out + o) = dk;
                 if (ep.drop_thi) drop_run<4>(gl, (uint32_t)o, ep);
                 u32x2_t gk = {pack_bf16x2(gl[0], gl[1]), pack_bf16x2(gl[2], gl[3])};
                 *(u32x2_t*)((bf16_t*)ep.out2 + o) = gk;
@@ -107,12 +119,17 @@ VA_DEVINL void store_tile(const f32x4_t (&acc)[TN][TM], const EpiArgs& ep, int M
                     for (int j = 0; j < 4; ++j) v[j] += rv[j];
                 }
                 *(f32x4_t*)((float*)ep.out + o) = (f32x4_t){v[0], v[1], v[2], v[3]};
-            } else {  // VA_EPI_GELU_BWD
+            } else {  // VA_EPI_GELU_BWD, VA_EPI_MUL_AUX
                 const u32x2_t pre = *(const u32x2_t*)(ep.aux + o);
                 const float p0 = __uint_as_float(pre[0] << 16), p1 = __uint_as_float(pre[0] & 0xffff0000u);
                 const float p2 = __uint_as_float(pre[1] << 16), p3 = __uint_as_float(pre[1] & 0xffff0000u);
-                float r[4] = {v[0] * gelu_erf_grad(p0), v[1] * gelu_erf_grad(p1), v[2] * gelu_erf_grad(p2),
-                              v[3] * gelu_erf_grad(p3)};
+                float r[4];
+                if (EPI == VA_EPI_MUL_AUX) {
+                    r[0] = v[0] * p0; r[1] = v[1] * p1; r[2] = v[2] * p2; r[3] = v[3] * p3;
+                } else {
+                    r[0] = v[0] * gelu_erf_grad(p0); r[1] = v[1] * gelu_erf_grad(p1);
+                    r[2] = v[2] * gelu_erf_grad(p2); r[3] = v[3] * gelu_erf_grad(p3);
+                }
                 if (ep.drop_thi) drop_run<4>(r, (uint32_t)o, ep);
                 u32x2_t pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
                 *(u32x2_t*)((bf16_t*)ep.out + o) = pk;
@@ -278,7 +295,7 @@ VA_DEVINL void store_tile_rows(Get get, const EpiArgs& ep, int M, int m_wave, in
     float bias[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) bias[q] = 0.f;
-    if (HAS_BIAS && EPI != VA_EPI_GELU_BWD && ep.bias != nullptr) {
+    if (HAS_BIAS && !epi_reads_aux(EPI) && ep.bias != nullptr) {
 #pragma unroll
         for (int q = 0; q < NV; q += 4) *(f32x4_t*)(bias + q) = *(const f32x4_t*)(ep.bias + col + q);
     }
@@ -289,14 +306,14 @@ VA_DEVINL void store_tile_rows(Get get, const EpiArgs& ep, int M, int m_wave, in
         const int m = m_wave + (i >> 2) * 16 + 4 * g + (i & 3);
         return (FULL_M || m < M) ? *(const pk_t*)(ep.aux + (size_t)m * ldc + col) : pk_t{};
     };
-    if (EPI == VA_EPI_GELU_BWD) aux_next = aux_row(0);
+    if (epi_reads_aux(EPI)) aux_next = aux_row(0);
 #pragma unroll
     for (int b = 0; b < TM; ++b)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m_wave + b * 16 + 4 * g + j;
             pk_t aux_cur = aux_next;
-            if (EPI == VA_EPI_GELU_BWD && 4 * b + j + 1 < 4 * TM) aux_next = aux_row(4 * b + j + 1);
+            if (epi_reads_aux(EPI) && 4 * b + j + 1 < 4 * TM) aux_next = aux_row(4 * b + j + 1);
             if (!FULL_M && m >= M) continue;
             const size_t o = (size_t)m * ldc + col;
             float v[NV];
@@ -311,15 +328,47 @@ VA_DEVINL void store_tile_rows(Get get, const EpiArgs& ep, int M, int m_wave, in
                 for (int q = 0; q < NV; ++q) gl[q] = gelu_erf(v[q]);
                 if (CAN_DROP && ep.drop_thi) drop_run<NV>(gl, (uint32_t)o, ep);
                 put_16(pack_run<NV>(gl), (pk_t*)((bf16_t*)(EPI == VA_EPI_BIAS_GELU ? ep.out2 : ep.out) + o), nt);
-            } else {  // VA_EPI_GELU_BWD
+            } else if (EPI == VA_EPI_BIAS_GELU_GRAD) {
+                float gl[NV], gd[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) gelu_erf_both(v[q], gl[q], gd[q]);
+                put_16(pack_run<NV>(gd), (pk_t*)((bf16_t*)ep.out + o), nt);
+                if (CAN_DROP && ep.drop_thi) drop_run<NV>(gl, (uint32_t)o, ep);
+                put_16(pack_run<NV>(gl), (pk_t*)((bf16_t*)ep.out2 + o), nt);
+            } else {  // VA_EPI_GELU_BWD, VA_EPI_MUL_AUX
                 float pre[NV], rr[NV];
                 unpack_run<NV>(aux_cur, pre);
 #pragma unroll
-                for (int q = 0; q < NV; ++q) rr[q] = v[q] * gelu_erf_grad(pre[q]);
+                for (int q = 0; q < NV; ++q) rr[q] = EPI == VA_EPI_MUL_AUX ? v[q] * pre[q] : v[q] * gelu_erf_grad(pre[q]);
                 if (CAN_DROP && ep.drop_thi) drop_run<NV>(rr, (uint32_t)o, ep);
                 put_16(pack_run<NV>(rr), (pk_t*)((bf16_t*)ep.out + o), nt);
             }
         }
+}
+
+// out = acc * aux for the four-wave kernel (a lane owns 8 consecutive columns of rows 4g + j of each 16-row block).  The
+// factor pieces of ALL the wave's rows are already in registers: the kernel requests them -- 32 loads in flight together
+// -- at the head of the tile's last stage, whose MFMAs cover most of the round trip (a load issued in the epilogue,
+// behind a store, would wait for that store too: memory operations retire in order, and with one wave per SIMD nothing
+// else covers the wait).  The next tile's first fragments are read after this epilogue, which frees the 128 registers.
+template <int TM, bool FULL_M, typename Get>
+VA_DEVINL void store_tile_mul_aux(Get get, const u32x4_t (&aux)[4 * TM], const EpiArgs& ep, int M, int m_wave, int n_wave,
+                                  int lane) {
+    const int ldc = ep.ldc;
+    const int r = lane & 15, g = lane >> 4;
+    const bool nt = ep.nt != 0;
+    const int col = n_wave + r * 8;
+#pragma unroll
+    for (int i = 0; i < 4 * TM; ++i) {
+        const int b = i >> 2, j = i & 3;
+        const int m = m_wave + b * 16 + 4 * g + j;
+        if (!FULL_M && m >= M) continue;
+        float f[8], v[8];
+        unpack_run<8>(aux[i], f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = get(q, b, j) * f[q];
+        put_16(pack_run<8>(v), (u32x4_t*)((bf16_t*)ep.out + (size_t)m * ldc + col), nt);
+    }
 }
 
 // Epilogue of the fused QKV projection + 3-D rotary embedding (swm:265-281 on the output of swm:300-308).  The 3072 output
@@ -751,6 +800,9 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     // that is the same for every tile (1024 chunks per operand per stage, 4 per thread: chunk q -> row q>>2,
     // slot q&3), and the stage's k offset as the scalar offset.
     constexpr bool ROPE = EPI == EPI_QKV_ROPE;
+    // epilogues that need the registers of the next tile's first fragments: the last stage reads none ahead, they are
+    // read after the epilogue (needs nk >= 6: checked by the host)
+    constexpr bool LATE_FRAGS = ROPE || EPI == VA_EPI_MUL_AUX;
     struct Tile {
         int m0, n0;
         __amdgpu_buffer_rsrc_t x, w;
@@ -836,12 +888,27 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
 #pragma unroll
             for (int j = 0; j < 8; ++j) sink[i][j] = (u32x4_t){0u, 0u, 0u, 0u};
     }
+    // VA_EPI_MUL_AUX: the current tile's factor pieces (see store_tile_mul_aux), this lane's pointer to the first of them
+    // and the number of the wave's 128 rows that exist
+    u32x4_t auxr[4 * TM];
+    const char* aux_tile = nullptr;      // wave-uniform: first of the wave's rows, first of its columns
+    const uint32_t aux_loff = (uint32_t)((4 * (lane >> 4) * ep.ldc + (lane & 15) * 8) * 2);   // the lane's byte offset from there
+    int aux_rows = 0;
     auto body = [&](auto parity, auto first, int next_slot, const Tile& lt, int kt_load, int load_slot, auto prefetch) {
         constexpr int P = decltype(parity)::value;
         constexpr bool FIRST = decltype(first)::value;
         // PREFETCH false (the last stage of a tile in the fused QKV + rotary build): the next tile's first fragments are
         // read after the epilogue instead -- that epilogue needs the 128 registers they would occupy across it
         constexpr bool PREFETCH = decltype(prefetch)::value;
+        if constexpr (!PREFETCH && EPI == VA_EPI_MUL_AUX) {
+#pragma unroll
+            for (int i = 0; i < 4 * TM; ++i) {
+                const int urow = (i >> 2) * 16 + (i & 3);          // uniform part of the row: scalar base + 32-bit lane offset
+                auxr[i] = urow + 4 * (lane >> 4) < aux_rows ? *(const u32x4_t*)(aux_tile + (size_t)urow * ep.ldc * 2 + aux_loff)
+                                                            : (u32x4_t){0u, 0u, 0u, 0u};
+            }
+            asm volatile("" ::: "memory");
+        }
         auto block = [&](auto bc) {
             constexpr int b = decltype(bc)::value;
 #pragma unroll
@@ -912,6 +979,13 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     const int first_ticket = draw();
     Tile cur;
     set_tile(v, cur);
+    auto aim_aux = [&](const Tile& t) {
+        if constexpr (EPI == VA_EPI_MUL_AUX) {
+            aux_tile = (const char*)(ep.aux + (size_t)(t.m0 + wm * 128) * ep.ldc + t.n0 + wn * 128);
+            aux_rows = M - (t.m0 + wm * 128);
+        }
+    };
+    aim_aux(cur);
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -937,7 +1011,8 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     // loads a stage needs are followed by two stages' loads AND those stores (32 instructions per wave for one
     // 2-byte output, 64 otherwise): that many may stay in flight, and the stores need not drain before the matrix
     // work resumes.  (An edge tile skips the stores of missing row blocks, so it gets the plain count.)
-    constexpr int STORES = (EPI == VA_EPI_BF16 || EPI == VA_EPI_GELU_BWD || EPI == VA_EPI_GELU_ONLY) ? 32 : 64;
+    // (the epilogues that read `aux` issue a load per store: 64 as well)
+    constexpr int STORES = (EPI == VA_EPI_BF16 || EPI == VA_EPI_GELU_ONLY) ? 32 : 64;
     constexpr int RELAXED = 2 * LPS + STORES < 63 ? 2 * LPS + STORES : 63;
     auto sync = [&](bool relaxed) {
         if (STAMP) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_body += now - t_last; t_last = now; }
@@ -968,7 +1043,7 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         stage_one(P1{}, No{}, 1, after_epilogue, Yes{});
         stage_one(P0{}, No{}, 2, after_epilogue, Yes{});
         stage_one(P1{}, No{}, 3, false, Yes{});
-        if constexpr (ROPE) {      // nk >= 6 (checked by the host): the last stage is peeled off and reads no fragments ahead
+        if constexpr (LATE_FRAGS) {      // nk >= 6 (checked by the host): the last stage is peeled off and reads no fragments ahead
             for (int kt = 4; kt + 2 < nk; kt += 2) {
                 stage_one(P0{}, No{}, kt, false, Yes{});
                 stage_one(P1{}, No{}, kt + 1, false, Yes{});
@@ -1040,14 +1115,17 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         } else
         {
             auto get = [&](int v, int b, int j) { return acc[v >> 2][v & 3][b][j]; };
-            if constexpr (ROPE) {
-                // accumulators are copied out where they are used, by statements the compiler keeps in order: left to
-                // itself it copies all 256 out first and spills forty of them around this (register-hungrier) epilogue
-                auto get_here = [&](int v, int b, int j) {
-                    float x;
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[v >> 2][v & 3][b][j]));
-                    return x;
-                };
+            // accumulators are copied out where they are used, by statements the compiler keeps in order: left to
+            // itself it copies all 256 out first and spills forty of them around a register-hungry epilogue
+            auto get_here = [&](int v, int b, int j) {
+                float x;
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[v >> 2][v & 3][b][j]));
+                return x;
+            };
+            if constexpr (EPI == VA_EPI_MUL_AUX) {
+                if (full) store_tile_mul_aux<TM, true>(get_here, auxr, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
+                else store_tile_mul_aux<TM, false>(get_here, auxr, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
+            } else if constexpr (ROPE) {
                 int a0, b0, seg, so;
                 qkv_rope_cols(cur.n0 / BN, wn, a0, b0, seg, so);
                 if (full) store_tile_qkv_rope<TM, true>(get_here, ep, M, cur.m0 + wm * 128, a0, b0, seg, so, lane);
@@ -1070,8 +1148,9 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         vn = collect(before(slot));
         }
         cur = nxt;
+        aim_aux(cur);
         after_epilogue = full;
-        if constexpr (ROPE) {      // the fragments of the next tile's first stage (landed since the last stage's wait + barrier)
+        if constexpr (LATE_FRAGS) {      // the fragments of the next tile's first stage (landed since the last stage's wait + barrier)
 #pragma unroll
             for (int a = 0; a < TN; ++a) wf[0][a] = frag_w(slot, a);
 #pragma unroll
@@ -1220,7 +1299,7 @@ int launch_epi(int tile, const bf16_t* X, const bf16_t* W, int M, int N, int K, 
         // The bias adds are compiled out only for the plain 2-byte output without a bias (the f32 epilogue keeps
         // them: its bias-free build schedules worse and measures slower than adding zeros).
         if (EPI == VA_EPI_BF16 && ep.bias == nullptr) return launch_quad<EPI, EPI != VA_EPI_BF16>(X, W, M, N, K, ldx, ldw, ep, stream);
-        return launch_quad<EPI, EPI != VA_EPI_GELU_BWD>(X, W, M, N, K, ldx, ldw, ep, stream);
+        return launch_quad<EPI, !epi_reads_aux(EPI)>(X, W, M, N, K, ldx, ldw, ep, stream);
     }
     if (tile == 1256) return launch_pair<256, 256, 2, 4, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
     return launch_pair<128, 128, 2, 2, EPI>(X, W, M, N, K, ldx, ldw, ep, stream);
@@ -1252,18 +1331,20 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
         const int64_t tiles256 = ((M + 255) / 256) * (N / 256);
         const bool big = N % 256 == 0 && M >= 2048 && K >= 128 && tiles256 >= 150;
         const bool quad = epilogue == VA_EPI_BF16 ||
-                          ((epilogue == VA_EPI_F32 || epilogue == VA_EPI_BIAS_GELU || epilogue == VA_EPI_GELU_ONLY) && drop_thresh16 == 0);
+                          ((epilogue == VA_EPI_F32 || epilogue == VA_EPI_BIAS_GELU || epilogue == VA_EPI_GELU_ONLY ||
+                            epilogue == VA_EPI_BIAS_GELU_GRAD || (epilogue == VA_EPI_MUL_AUX && K >= 192)) && drop_thresh16 == 0);
         tile = !big ? 128 : quad ? 4256 : 256;
     }
     VA_CHECK_ARG(tile == 128 || ((tile == 256 || tile == 1256 || tile == 2256 || tile == 4256) && N % 256 == 0 && K >= 128),
                  "va_gemm_nt: tile %d not usable with N=%lld K=%lld", tile, (long long)N, (long long)K);
     VA_CHECK_ARG(drop_thresh16 == 0 || tile < 4256, "va_gemm_nt_dropout: the four-wave kernel (tile %d) has no dropout epilogue", tile);
+    VA_CHECK_ARG(!(tile == 4256 && epilogue == VA_EPI_MUL_AUX && K < 192), "va_gemm_nt: the four-wave kernel's multiply epilogue needs K >= 192");
     // non-temporal stores for outputs beyond the last-level cache's reach (256 MB; VA_GEMM_NT_MIN_MB overrides, 0 = always)
     static const long nt_min_mb = [] {
         const char* e = getenv("VA_GEMM_NT_MIN_MB");
         return e ? atol(e) : 300L;
     }();
-    const int64_t out_bytes = M * N * (epilogue == VA_EPI_F32 ? 4 : 2) * (epilogue == VA_EPI_BIAS_GELU ? 2 : 1);
+    const int64_t out_bytes = M * N * (epilogue == VA_EPI_F32 ? 4 : 2) * (epi_two_outputs(epilogue) ? 2 : 1);
     EpiArgs ep{out, out2, bias, resid, (const bf16_t*)aux, (int)ldc, drop_key, drop_thresh16 << 16,
                va_drop_scale(drop_thresh16), out_bytes >= nt_min_mb * (1ll << 20) ? 1 : 0, nullptr, nullptr, 0, 0, 0};
     const bf16_t* X = (const bf16_t*)x;
@@ -1282,6 +1363,12 @@ static int gemm_nt_entry(const void* x, const void* w, int64_t M, int64_t N, int
         case VA_EPI_GELU_BWD:
             VA_CHECK_ARG(aux, "va_gemm_nt: GELU-backward epilogue needs the saved pre-activation");
             return launch_epi<VA_EPI_GELU_BWD>(tile, X, W, (int)M, (int)N, (int)K, (int)ldx, (int)ldw, ep, stream);
+        case VA_EPI_BIAS_GELU_GRAD:
+            VA_CHECK_ARG(out2 && bias, "va_gemm_nt: bias+GELU epilogue needs out2 and bias");
+            return launch_epi<VA_EPI_BIAS_GELU_GRAD>(tile, X, W, (int)M, (int)N, (int)K, (int)ldx, (int)ldw, ep, stream);
+        case VA_EPI_MUL_AUX:
+            VA_CHECK_ARG(aux, "va_gemm_nt: the multiply epilogue needs its factor matrix");
+            return launch_epi<VA_EPI_MUL_AUX>(tile, X, W, (int)M, (int)N, (int)K, (int)ldx, (int)ldw, ep, stream);
         default:
             va_set_error("va_gemm_nt: unknown epilogue %d", epilogue);
             return VA_ERR_INVALID;

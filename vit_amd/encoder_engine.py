@@ -33,6 +33,12 @@ from . import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
 LN_EPS = 1e-6
+# What the fc1 forward keeps for the backward pass: GELU'(pre-activation), consumed by a multiply epilogue (default), or,
+# with VIT_AMD_KEEP_PREACT=1, the pre-activation itself, consumed by the epilogue that evaluates GELU' (for A/B timing).
+import os as _os
+_KEEP_PREACT = _os.environ.get("VIT_AMD_KEEP_PREACT", "0") == "1"
+_EPI_FC1_KEEP = ops.EPI_BIAS_GELU if _KEEP_PREACT else ops.EPI_BIAS_GELU_GRAD
+_EPI_FC2_BWD = ops.EPI_GELU_BWD if _KEEP_PREACT else ops.EPI_MUL_AUX
 
 BLOCK_PARAM_NAMES = ("norm1.weight", "norm1.bias", "attn.qkv_proj.weight", "attn.out_proj.weight",
                      "norm2.weight", "norm2.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias")
@@ -345,8 +351,10 @@ class EncoderEngine:
         act = buf("act", 4 * D, BF16)
         # both MLP dropouts ride in the GEMM epilogues; the saved activation is the dropped one
         if keep:
+            # what the backward pass needs of the pre-activation is GELU'(pre): the epilogue that has exp and rcp of it in
+            # registers anyway stores that (same bytes), and the backward epilogue is a multiplication
             pre = torch.empty(M, 4 * D, dtype=BF16, device=dev)
-            ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BIAS_GELU, pre, out2=act,
+            ops.gemm_nt(ln2, Wc.fwd(p + "fc1", P[p + "mlp.0.weight"]), _EPI_FC1_KEEP, pre, out2=act,
                         bias=P[p + "mlp.0.bias"], drop_key=k1, drop_p=p1)
         else:           # nothing is kept for a backward: the pre-activation (half of this GEMM's output bytes) is not written
             pre = None
@@ -428,8 +436,8 @@ class EncoderEngine:
             ka, k1, k2 = drop.keys[i] if drop is not None else (0, 0, 0)
             # ---- MLP (g_bf arrives with the fc2 dropout's mask already applied; g_a is the undropped gradient)
             g_mlp = g_bf
-            ops.gemm_nt(g_mlp, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), ops.EPI_GELU_BWD, d_wide, aux=s.pre,
-                        drop_key=k1, drop_p=p1)       # the mask commutes with the GELU derivative
+            ops.gemm_nt(g_mlp, Wc.bwd(p + "fc2", P[p + "mlp.3.weight"]), _EPI_FC2_BWD, d_wide, aux=s.pre,
+                        drop_key=k1, drop_p=p1)       # s.pre holds GELU'(pre-activation); the mask commutes with it
             ops.gemm_tn_accum(g_mlp, s.act, grads[p + "mlp.3.weight"])     # the bias gradient came with g_bf
             ops.gemm_nt(d_wide, Wc.bwd(p + "fc1", P[p + "mlp.0.weight"]), ops.EPI_BF16, d_small)
             ops.gemm_tn_accum(d_wide, s.ln2, grads[p + "mlp.0.weight"], dbias=grads[p + "mlp.0.bias"])

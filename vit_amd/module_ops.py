@@ -185,7 +185,8 @@ class MlpFn(torch.autograd.Function):
         pre = torch.empty(M, hidden, dtype=BF16, device=h.device)
         act = torch.empty(M, hidden, dtype=BF16, device=h.device)
         (k1, p1), (k2, p2) = spec.drop1, spec.drop2
-        ops.gemm_nt(hb, spec.cache.fwd(spec.key + "fc1", w1), ops.EPI_BIAS_GELU, pre, out2=act, bias=b1.detach(),
+        # `pre` receives GELU'(pre-activation), which is all the backward pass needs of it
+        ops.gemm_nt(hb, spec.cache.fwd(spec.key + "fc1", w1), ops.EPI_BIAS_GELU_GRAD, pre, out2=act, bias=b1.detach(),
                     drop_key=k1, drop_p=p1)
         out = torch.empty(M, w2.shape[0], dtype=F32, device=h.device)
         r2 = None if resid is None else resid.detach().to(F32).contiguous().view(M, w2.shape[0])
@@ -207,7 +208,7 @@ class MlpFn(torch.autograd.Function):
         db2 = torch.zeros(Dout, dtype=F32, device=g.device)
         ops.colsum_accum(g_bf, db2)
         d_wide = torch.empty(M, hidden, dtype=BF16, device=g.device)
-        ops.gemm_nt(g_bf, spec.cache.bwd(spec.key + "fc2", w2), ops.EPI_GELU_BWD, d_wide, aux=pre, drop_key=k1, drop_p=p1)
+        ops.gemm_nt(g_bf, spec.cache.bwd(spec.key + "fc2", w2), ops.EPI_MUL_AUX, d_wide, aux=pre, drop_key=k1, drop_p=p1)
         dw2 = torch.zeros(Dout, hidden, dtype=F32, device=g.device)
         ops.gemm_tn_accum(g_bf, act, dw2)
         dh = None

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import check
 
-EPI_BF16, EPI_BIAS_GELU, EPI_F32, EPI_GELU_BWD, EPI_GELU_ONLY = 0, 1, 2, 3, 4
+EPI_BF16, EPI_BIAS_GELU, EPI_F32, EPI_GELU_BWD, EPI_GELU_ONLY, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 BF16, F32 = torch.bfloat16, torch.float32
 
 
