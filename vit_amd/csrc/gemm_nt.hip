@@ -381,39 +381,41 @@ VA_DEVINL void store_tile_mul_aux(Get get, const u32x4_t (&aux)[4 * TM], const E
 // table row, or -1 for the value third.  Rotation in f32 on the accumulators (the separate pass rotates the rounded
 // bf16 product): y_a = a cos - b sin, y_b = b cos + a sin.
 template <int TM, bool FULL_M, typename Get>
-VA_DEVINL void store_tile_qkv_rope(Get get, const EpiArgs& ep, int M, int m_wave, int col_a, int col_b, int seg, int seg_off,
-                                   int lane) {
+VA_DEVINL void store_tile_qkv_rope(Get get, const int (&code)[TM * 4], const EpiArgs& ep, int M, int m_wave, int col_a, int col_b,
+                                   int seg, int seg_off, int lane) {
     const int ldc = ep.ldc;
     const int r = lane & 15, g = lane >> 4;
     const bool nt = ep.nt != 0;
     const int tab_sz = ep.rope_tp * 128 + (ep.rope_hp + ep.rope_wp) * 192;
     const bool rot = seg >= 0;
-    // every row's table offset first (one 4-byte load per row, all in flight together), then the table rows one output row
-    // ahead of their use: a load issued after a store would wait for that store too (memory operations retire in order)
+    // `code`: every row's packed position, requested by the kernel at the head of the tile's last stage (0 for rows past
+    // M).  The table rows are requested DEPTH output rows ahead of their use: each is a cache round trip that nothing else
+    // covers with one wave per SIMD, and a load issued behind a store waits for that store too (memory operations retire
+    // in order), which the distance also relaxes.
     const int base = seg == 0 ? 0 : seg == 1 ? ep.rope_tp * 128 : ep.rope_tp * 128 + ep.rope_hp * 192;
     const int stride = seg == 0 ? 128 : 192, shift = seg == 0 ? 0 : seg == 1 ? 10 : 20;
+    constexpr int DEPTH = 6;
     int toff[TM * 4];
 #pragma unroll
-    for (int i = 0; i < TM * 4; ++i) {
-        const int m = m_wave + (i >> 2) * 16 + 4 * g + (i & 3);
-        toff[i] = 0;
-        if (rot && (FULL_M || m < M)) toff[i] = ep.rope_pos[m];
-    }
+    for (int i = 0; i < TM * 4; ++i) toff[i] = base + ((code[i] >> shift) & 1023) * stride + seg_off + 4 * r;
+    f32x4_t cs_q[DEPTH], sn_q[DEPTH];
 #pragma unroll
-    for (int i = 0; i < TM * 4; ++i) toff[i] = base + ((toff[i] >> shift) & 1023) * stride + seg_off + 4 * r;
-    f32x4_t cs_next = {1.f, 1.f, 1.f, 1.f}, sn_next = {0.f, 0.f, 0.f, 0.f};
-    if (rot) {
-        cs_next = *(const f32x4_t*)(ep.rope_tables + toff[0]);
-        sn_next = *(const f32x4_t*)(ep.rope_tables + tab_sz + toff[0]);
+    for (int d = 0; d < DEPTH; ++d) {
+        cs_q[d] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+        sn_q[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (rot) {
+            cs_q[d] = *(const f32x4_t*)(ep.rope_tables + toff[d]);
+            sn_q[d] = *(const f32x4_t*)(ep.rope_tables + tab_sz + toff[d]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM * 4; ++i) {
         const int b = i >> 2, j = i & 3;
         const int m = m_wave + b * 16 + 4 * g + j;
-        const f32x4_t cs = cs_next, sn = sn_next;
-        if (rot && i + 1 < TM * 4) {
-            cs_next = *(const f32x4_t*)(ep.rope_tables + toff[i + 1]);
-            sn_next = *(const f32x4_t*)(ep.rope_tables + tab_sz + toff[i + 1]);
+        const f32x4_t cs = cs_q[i % DEPTH], sn = sn_q[i % DEPTH];
+        if (rot && i + DEPTH < TM * 4) {
+            cs_q[i % DEPTH] = *(const f32x4_t*)(ep.rope_tables + toff[i + DEPTH]);
+            sn_q[i % DEPTH] = *(const f32x4_t*)(ep.rope_tables + tab_sz + toff[i + DEPTH]);
         }
         if (!FULL_M && m >= M) continue;
         float a[4], bb[4];
@@ -890,6 +892,8 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     }
     // VA_EPI_MUL_AUX: the current tile's factor pieces (see store_tile_mul_aux), this lane's pointer to the first of them
     // and the number of the wave's 128 rows that exist
+    int rope_code[4 * TM];               // EPI_QKV_ROPE: packed positions of the wave's rows (see store_tile_qkv_rope)
+    const int32_t* pos_tile = nullptr;   // wave-uniform: the first of them
     u32x4_t auxr[4 * TM];
     const char* aux_tile = nullptr;      // wave-uniform: first of the wave's rows, first of its columns
     const uint32_t aux_loff = (uint32_t)((4 * (lane >> 4) * ep.ldc + (lane & 15) * 8) * 2);   // the lane's byte offset from there
@@ -900,6 +904,14 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
         // PREFETCH false (the last stage of a tile in the fused QKV + rotary build): the next tile's first fragments are
         // read after the epilogue instead -- that epilogue needs the 128 registers they would occupy across it
         constexpr bool PREFETCH = decltype(prefetch)::value;
+        if constexpr (!PREFETCH && ROPE) {
+#pragma unroll
+            for (int i = 0; i < 4 * TM; ++i) {
+                const int urow = (i >> 2) * 16 + (i & 3);
+                rope_code[i] = urow + 4 * (lane >> 4) < aux_rows ? pos_tile[urow + 4 * (lane >> 4)] : 0;
+            }
+            asm volatile("" ::: "memory");
+        }
         if constexpr (!PREFETCH && EPI == VA_EPI_MUL_AUX) {
 #pragma unroll
             for (int i = 0; i < 4 * TM; ++i) {
@@ -982,6 +994,10 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
     auto aim_aux = [&](const Tile& t) {
         if constexpr (EPI == VA_EPI_MUL_AUX) {
             aux_tile = (const char*)(ep.aux + (size_t)(t.m0 + wm * 128) * ep.ldc + t.n0 + wn * 128);
+            aux_rows = M - (t.m0 + wm * 128);
+        }
+        if constexpr (ROPE) {
+            pos_tile = ep.rope_pos + (t.m0 + wm * 128);
             aux_rows = M - (t.m0 + wm * 128);
         }
     };
@@ -1128,8 +1144,8 @@ __global__ __launch_bounds__(256) void gemm_nt_quad_kernel(const bf16_t* __restr
             } else if constexpr (ROPE) {
                 int a0, b0, seg, so;
                 qkv_rope_cols(cur.n0 / BN, wn, a0, b0, seg, so);
-                if (full) store_tile_qkv_rope<TM, true>(get_here, ep, M, cur.m0 + wm * 128, a0, b0, seg, so, lane);
-                else store_tile_qkv_rope<TM, false>(get_here, ep, M, cur.m0 + wm * 128, a0, b0, seg, so, lane);
+                if (full) store_tile_qkv_rope<TM, true>(get_here, rope_code, ep, M, cur.m0 + wm * 128, a0, b0, seg, so, lane);
+                else store_tile_qkv_rope<TM, false>(get_here, rope_code, ep, M, cur.m0 + wm * 128, a0, b0, seg, so, lane);
             } else {
                 if (full) store_tile_rows<EPI, TM, 8, true, HAS_BIAS, true, false>(get, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
                 else store_tile_rows<EPI, TM, 8, false, HAS_BIAS, false, false>(get, ep, M, cur.m0 + wm * 128, cur.n0 + wn * 128, lane);
