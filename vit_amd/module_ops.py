@@ -182,17 +182,23 @@ class MlpFn(torch.autograd.Function):
         lead, D = h.shape[:-1], h.shape[-1]
         hb = _as_operand(h.detach().reshape(-1, D))
         M, hidden = hb.shape[0], w1.shape[0]
-        pre = torch.empty(M, hidden, dtype=BF16, device=h.device)
         act = torch.empty(M, hidden, dtype=BF16, device=h.device)
         (k1, p1), (k2, p2) = spec.drop1, spec.drop2
-        # `pre` receives GELU'(pre-activation), which is all the backward pass needs of it
-        ops.gemm_nt(hb, spec.cache.fwd(spec.key + "fc1", w1), ops.EPI_BIAS_GELU_GRAD, pre, out2=act, bias=b1.detach(),
-                    drop_key=k1, drop_p=p1)
+        if any(ctx.needs_input_grad[:6]):
+            # `pre` receives GELU'(pre-activation), which is all the backward pass needs of it
+            pre = torch.empty(M, hidden, dtype=BF16, device=h.device)
+            ops.gemm_nt(hb, spec.cache.fwd(spec.key + "fc1", w1), ops.EPI_BIAS_GELU_GRAD, pre, out2=act, bias=b1.detach(),
+                        drop_key=k1, drop_p=p1)
+        else:       # a pass that keeps nothing for a backward (no_grad, frozen module): half the output bytes
+            pre = None
+            ops.gemm_nt(hb, spec.cache.fwd(spec.key + "fc1", w1), ops.EPI_GELU_ONLY, act, bias=b1.detach(),
+                        drop_key=k1, drop_p=p1)
         out = torch.empty(M, w2.shape[0], dtype=F32, device=h.device)
         r2 = None if resid is None else resid.detach().to(F32).contiguous().view(M, w2.shape[0])
         ops.gemm_nt(act, spec.cache.fwd(spec.key + "fc2", w2), ops.EPI_F32, out, bias=b2.detach(), resid=r2,
                     drop_key=k2, drop_p=p2)
-        ctx.save_for_backward(hb, pre, act, w1, w2)
+        if pre is not None:
+            ctx.save_for_backward(hb, pre, act, w1, w2)
         ctx.spec, ctx.lead, ctx.h_dtype, ctx.has_resid = spec, lead, h.dtype, resid is not None
         return out.view(*lead, w2.shape[0])
 
