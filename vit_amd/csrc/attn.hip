@@ -1178,6 +1178,8 @@ int check_common(const char* who, int64_t B, int64_t N, int64_t H, int64_t hd, i
     VA_CHECK_ARG(ldqkv >= H * hd && ldo >= H * hd, "%s: leading dimension smaller than H*hd", who);
     VA_CHECK_ARG(ldqkv % 8 == 0 && ldo % 8 == 0, "%s: leading dimensions must keep 16-byte alignment", who);
     VA_CHECK_ARG(B * H < 65536 && N < (1 << 24), "%s: B*H or N too large for the launch grid", who);
+    // a 64-row tile is addressed through one buffer descriptor with 32-bit offsets
+    VA_CHECK_ARG(ldqkv < (1 << 23) && ldo < (1 << 23), "%s: leading dimension too large", who);
     return VA_OK;
 }
 
