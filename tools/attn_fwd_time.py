@@ -1,5 +1,5 @@
 """Times va_attn_fwd at the ViT-L shape (B = 32, N = 2048, 16 heads of 64) and reports its distance from an f32 softmax
-attention on one head-batch.  VA_ATTN_FWD_Q32=1 in the environment keeps the 32-queries-per-wave kernel (A/B)."""
+attention on one head-batch; with VIT_AMD_LIB pointing at another build of the library this is the A/B of the kernel."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,4 +22,4 @@ for rnd in range(3):
     s.record()
     for _ in range(50): ops.attn_fwd(qkv, B, N, H, o, lse)
     e.record(); torch.cuda.synchronize()
-    print("q32" if os.environ.get("VA_ATTN_FWD_Q32") == "1" else "q64", "fwd", round(s.elapsed_time(e) / 50, 4), "ms", flush=True)
+    print(os.environ.get("VIT_AMD_LIB", "in-tree build"), "fwd", round(s.elapsed_time(e) / 50, 4), "ms", flush=True)
